@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- TsdfVolume::integrate throughput on MI355X (BASELINE.json: voxel updates/sec).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch of synthetic input: one 640x480 depth frame
+(already converted to the half ray-distance image and resident in HBM) integrated into the rank's
+z-slab of the TSDF volume.  N = 1 is BASELINE.json configs[1]: 512^3 volume, scene S0 ("wall":
+every voxel is in view and in front of the surface, so every voxel is read, updated and written).
+N > 1: the volume grows with N (z-slab sharding, 512^3 voxels per rank, no data-path collective:
+every rank integrates its own layers from the same frame) -> weak scaling.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      HBM roofline of the integrate kernel (algorithmic bytes / mean launch time)
+  cpu_baseline  the scalar CPU oracle timed on this box's host cores (N = 1, rank 0 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+VOXELS_PER_RANK_EDGE = 512
+
+# global volume per world size: 512^3 voxels per rank, z kept as shallow as possible
+GLOBAL_DIMS = {1: (512, 512, 512), 2: (1024, 512, 512), 4: (1024, 1024, 512), 8: (1024, 1024, 1024)}
+
+
+def wall_scene(dims, voxel):
+    """Scene S0 generalised to any volume extent: camera centred on the x/y extent, far enough back
+    that the near face projects inside the image, wall 0.3 m behind the far face."""
+    from yak_amd import synth
+
+    ex, ey, ez = (d * voxel for d in dims)
+    back = 3.7 * max(ex, ey) / 3.0
+    eye = np.array([ex / 2, ey / 2, -back])
+    R_c2v = np.eye(3)
+    depth = synth.render_depth(R_c2v, eye, planes=[((0, 0, ez + 0.3), (0, 0, 1))])
+    R, t = synth.vol2cam(R_c2v, eye)
+    return depth, R, t
+
+
+def cpu_baseline(dims, vs, tr, dists, R, t, intr, max_weight):
+    """The scalar oracle (kind 'port': the reference's integrate is CUDA-only) on the host cores."""
+    import oracle
+
+    threads = min(oracle.max_threads(), os.cpu_count() or 1)
+    layers = 128  # bounded sample: the first 128 of 512 layers, same frame, same pose
+    n = dims[0] * dims[1] * layers
+    slab = np.zeros(n, dtype=np.uint32)
+    t0 = time.perf_counter()
+    _, upd1 = oracle.integrate(slab, dims, vs, tr, max_weight, dists, R, t, intr, z0=0, z1=layers, nthreads=1)
+    t1 = time.perf_counter() - t0
+    reps, upd, tm = 0, 0, 0.0
+    while tm < 4.0 and reps < 8:
+        slab[:] = 0
+        t0 = time.perf_counter()
+        _, u = oracle.integrate(slab, dims, vs, tr, max_weight, dists, R, t, intr, z0=0, z1=layers, nthreads=threads)
+        tm += time.perf_counter() - t0
+        upd += u
+        reps += 1
+    return {
+        "value": round(upd / tm / 1e9, 4),
+        "unit": "Gvox/s",
+        "cores": threads,
+        "kind": "port",
+        "value_1thread": round(upd1 / t1 / 1e9, 4),
+        "sample": "scalar C oracle (oracle/yak_oracle.c, OpenMP over y), same S0 frame, layers [0,%d) of the "
+                  "%dx%dx%d volume (%d voxels), %d repetitions at %d threads + 1 at 1 thread" % (
+                      layers, dims[0], dims[1], dims[2], n, reps, threads),
+    }
+
+
+def load_traffic(workload_key):
+    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        ent = rec.get(workload_key)
+        return ent.get("hbm_bytes_per_launch") if ent else None
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--scene", default="s0", choices=["s0", "s1"], help="s1 = sphere+wall (partial updates); N=1 only")
+    ap.add_argument("--z-chunk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    from yak_amd import capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- workload ---------------------------------------------------------------------------------
+    if world not in GLOBAL_DIMS:
+        sys.exit("supported world sizes: %s" % sorted(GLOBAL_DIMS))
+    dims = GLOBAL_DIMS[world]
+    voxel = synth.VOLUME_SIZE_M / VOXELS_PER_RANK_EDGE
+    _, _, tr = synth.volume_geometry(VOXELS_PER_RANK_EDGE)
+    vs = (voxel, voxel, voxel)
+    layers = dims[2] // world
+    z0, z1 = rank * layers, (rank + 1) * layers
+    slab_voxels = dims[0] * dims[1] * layers
+
+    if args.scene == "s1" and world == 1:
+        depth, R, t = synth.scene_s1()
+    else:
+        depth, R, t = wall_scene(dims, voxel)
+    intr = synth.INTR
+    rows, cols = depth.shape
+
+    ctx = capi.Context(local_rank)  # launches on torch's current stream
+    if args.z_chunk:
+        ctx.set_option("z_chunk", args.z_chunk)
+    d_depth = torch.from_numpy(depth.view(np.int16)).cuda()
+    d_dists = torch.empty_like(d_depth)
+    ctx.compute_dists(d_depth.data_ptr(), cols * 2, d_dists.data_ptr(), cols * 2, rows, cols, intr)
+    vol = torch.empty(slab_voxels, dtype=torch.int32, device="cuda")
+    desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT, z0, z1)
+    Rf = R.reshape(-1)
+
+    def step():
+        ctx.integrate(desc, d_dists.data_ptr(), cols * 2, rows, cols, Rf, t, intr)
+
+    # voxels updated per step on this rank: count them once (from a cleared volume every updated
+    # voxel ends with weight 1); the count is the same every step because the frame is the same
+    ctx.clear_volume(desc)
+    step()
+    torch.cuda.synchronize()
+    updated = int(((vol >> 16) == 1).sum().item())
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream, over the timed region
+
+    totals = torch.tensor([elapsed, float(updated), kernel_ms], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        mx = totals.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = totals.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, kernel_ms = float(mx[0]), float(mx[2])
+        updated_total = int(sm[1])
+    else:
+        updated_total = updated
+
+    if rank == 0:
+        gvox = updated_total * args.steps / elapsed / 1e9
+        # algorithmic bytes of ONE launch on ONE GPU: 4 B read + 4 B written per
+        # updated voxel + one pass over the half ray-distance image
+        alg_bytes = 8 * updated + 2 * rows * cols
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        workload = "%dx%dx%d volume (%d^3 voxels per GPU, z-slabs), one %dx%d synthetic depth frame per step, " \
+                   "scene %s, integrate only" % (dims[0], dims[1], dims[2], VOXELS_PER_RANK_EDGE, cols, rows,
+                                                 "S0 wall (every voxel updates)" if args.scene == "s0" or world > 1
+                                                 else "S1 sphere+wall")
+        out = {
+            "metric": "voxel updates/sec",
+            "value": round(gvox, 3),
+            "unit": "Gvox/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": workload, "voxels_updated_per_step": updated_total,
+                       "voxel_bytes": 4, "parallelism": "z-slab x%d" % world},
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": load_traffic("integrate_%s_n%d" % (args.scene, world)),
+                "kernel": "integrate_kernel<4,ZU,nt>",
+                "kernel_ms": round(kernel_ms, 5),
+                "algorithmic_bytes_per_launch": alg_bytes,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            dists_host = d_dists.cpu().numpy().view(np.uint16)
+            out["cpu_baseline"] = cpu_baseline(dims, vs, tr, dists_host, R, t, intr, synth.MAX_WEIGHT)
+        print(json.dumps(out), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+/*
+ * yakhip.h -- C ABI of the MI355X (gfx950) TSDF fusion engine for Yak.
+ *
+ * This is the drop-in seam: each entry point replaces one free function of the
+ * reference's device layer `kfusion::device::*` (yak/include/yak/kfusion/internal.hpp:124-193)
+ * or one method of its device-memory layer (yak/src/kfusion/device_memory.cpp).  The host
+ * classes of the reference (kfusion::cuda::TsdfVolume, KinFu, yak::FusionServer) already
+ * reduce everything to the plain pointers, dims and 3x4 pose floats that cross this boundary.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, POD structs.  No C++ types, no exceptions, no process globals.
+ *   - every call returns 0 on success, a negative YAKHIP_E* for a rejected argument, or a
+ *     positive hipError_t.  yakhip_last_error() gives the text (thread-local).  Nothing here
+ *     ever calls exit() (the reference's cudaSafeCall does: device_memory.cpp:7-11).
+ *   - all device work is enqueued on the context's stream and returns immediately; call
+ *     yakhip_ctx_synchronize() where the reference had cudaDeviceSynchronize()
+ *     (tsdf_volume.cu:139, imgproc.cpp:21).
+ *   - one context = one GPU = one caller thread at a time (same contract as yak_server.h:22).
+ *   - R is a row-major 3x3 rotation, t a translation, exactly the `device::Aff3f` the
+ *     reference builds with device_cast (yak/include/yak/kfusion/precomp.hpp:15-30).
+ *   - intr = {fx, fy, cx, cy} (kfusion::Intr, yak/include/yak/kfusion/types.hpp:18-25).
+ *
+ * All file:line citations are relative to /root/reference/.
+ */
+#ifndef YAKHIP_H_
+#define YAKHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YAKHIP_OK 0
+#define YAKHIP_EINVAL (-1)   /* bad argument (null pointer, non-positive size, bad range) */
+#define YAKHIP_EALIGN (-2)   /* pointer / pitch not aligned as required */
+#define YAKHIP_ENOGPU (-3)   /* no usable HIP device */
+#define YAKHIP_ERANGE (-4)   /* value outside what the kernels support (e.g. max_weight > 32767) */
+
+typedef struct yakhip_ctx yakhip_ctx;
+
+/*
+ * A z-slab view of a TSDF volume: replaces `kfusion::device::TsdfVolume`
+ * (yak/include/yak/kfusion/internal.hpp:42-67).
+ *
+ * Voxel = 4 bytes: bytes 0-1 IEEE half tsdf, bytes 2-3 int16 weight
+ * (yak/include/yak/kfusion/cuda/device.hpp:68-81; yak/include/yak/kfusion/tsdf_container.h:45-49).
+ * Layout x fastest, z slowest: offset(x,y,z) = x + y*dims[0] + z*dims[0]*dims[1] (device.hpp:21-24).
+ *
+ * `data` points at layer z0; the view owns layers [z0, z1) of a volume whose full
+ * extent is dims[].  A single-GPU volume is the slab z0 = 0, z1 = dims[2].  A slab
+ * is one contiguous byte range, so concatenating slabs in z order is the whole volume.
+ */
+typedef struct yakhip_volume
+{
+  void* data;           /* device pointer, 4-byte aligned (16-byte aligned enables the wide path) */
+  int dims[3];          /* full volume extent in voxels: X, Y, Z */
+  int z0, z1;           /* layers held by `data`: 0 <= z0 < z1 <= dims[2] */
+  float voxel_size[3];  /* metres per voxel (TsdfVolume::getVoxelSize, yak/src/kfusion/tsdf_volume.cpp:45-48) */
+  float trunc_dist;     /* metres (tsdf_volume.cpp:62-67) */
+  int max_weight;       /* 1..32767 */
+} yakhip_volume;
+
+/* ---- context ------------------------------------------------------------------------------ */
+
+/* Replaces kfusion::cuda::setDevice (yak/src/kfusion/core.cpp:23) + implicit default-stream use.
+ * Creates a non-blocking stream owned by the context. */
+int yakhip_ctx_create(yakhip_ctx** out, int device);
+int yakhip_ctx_destroy(yakhip_ctx* ctx);
+/* Borrow a caller-owned hipStream_t (e.g. the host framework's current stream); NULL = back to own. */
+int yakhip_ctx_set_stream(yakhip_ctx* ctx, void* hip_stream);
+/* Replaces cuda::waitAllDefaultStream (yak/src/kfusion/imgproc.cpp:21) and the
+ * cudaDeviceSynchronize at yak/src/cuda/tsdf_volume.cu:139. */
+int yakhip_ctx_synchronize(yakhip_ctx* ctx);
+/* Replaces getCudaEnabledDeviceCount / getDeviceName (yak/src/kfusion/core.cpp:8-21, 25-32). */
+int yakhip_device_count(int* count);
+int yakhip_device_name(int device, char* buf, size_t buflen);
+const char* yakhip_last_error(void);
+/* Engine knobs that are not part of the reference's API.  Keys: "z_chunk" (layers walked by one
+ * workgroup, 0 = auto), "nontemporal" (0/1).  Unknown key -> YAKHIP_EINVAL. */
+int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value);
+
+/* ---- device memory: replaces DeviceMemory / DeviceMemory2D
+ *      (yak/src/kfusion/device_memory.cpp:85-103 create, :129-138 upload/download,
+ *       :196-215 create 2-D pitched, :244-256 upload/download 2-D) ----------------------------- */
+int yakhip_malloc(yakhip_ctx* ctx, void** ptr, size_t bytes);
+int yakhip_malloc_pitch(yakhip_ctx* ctx, void** ptr, size_t* pitch_bytes, size_t width_bytes, size_t rows);
+int yakhip_free(yakhip_ctx* ctx, void* ptr);
+int yakhip_upload(yakhip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int yakhip_download(yakhip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int yakhip_upload_2d(yakhip_ctx* ctx, void* dst_dev, size_t dst_pitch, const void* src_host, size_t src_pitch,
+                     size_t width_bytes, size_t rows);
+int yakhip_download_2d(yakhip_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_dev, size_t src_pitch,
+                       size_t width_bytes, size_t rows);
+
+/* ---- hot path ----------------------------------------------------------------------------- */
+
+/* Replaces kfusion::device::clear_volume (internal.hpp:125; yak/src/cuda/tsdf_volume.cu:14-40):
+ * every voxel of the slab <- pack_tsdf(0, 0) = 0x00000000. */
+int yakhip_clear_volume(yakhip_ctx* ctx, const yakhip_volume* vol);
+
+/* Replaces kfusion::device::compute_dists (internal.hpp:150; yak/src/cuda/imgproc.cu:259-283):
+ * dists(y,x) = half_rn(depth_mm(y,x) * sqrt(xl^2 + yl^2 + 1) * 0.001), xl = (x - cx)/fx.
+ * depth: uint16 millimetres, dists: IEEE half bits; both row-pitched (pitch in bytes, even). */
+int yakhip_compute_dists(yakhip_ctx* ctx, const void* depth_dev, size_t depth_pitch, void* dists_dev,
+                         size_t dists_pitch, int rows, int cols, const float intr[4]);
+
+/* Replaces kfusion::device::integrate (internal.hpp:126; yak/src/cuda/tsdf_volume.cu:51-140):
+ * projective TSDF update of every voxel of the slab from one ray-distance image.
+ * R,t = vol2cam (volume frame -> camera frame) as built at yak/src/kfusion/tsdf_volume.cpp:97-104.
+ * Bit-identical, voxel for voxel, to the same layers of a whole-volume run (the camera-space
+ * position is accumulated from z = 0 exactly as tsdf_volume.cu:76 does). */
+int yakhip_integrate(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dists_dev, size_t dists_pitch, int rows,
+                     int cols, const float R[9], const float t[3], const float intr[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YAKHIP_H_ */

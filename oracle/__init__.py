@@ -1,0 +1,136 @@
+"""ctypes view of the CPU oracle (oracle/liboracle.so) and of oracle/_ref/libyakref.so.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product package `yak_amd`.
+See oracle/yak_oracle.h for the parity status ("parity unpinned" for integrate).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+_REF = os.path.join(_HERE, "_ref", "libyakref.so")
+
+
+def build(force=False):
+    """Compile liboracle.so (and _ref when /root/reference is present)."""
+    if force or not os.path.exists(_LIB) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB)
+        for f in os.listdir(_HERE)
+        if f.endswith((".c", ".h"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"])
+    if os.path.isdir("/root/reference/yak"):
+        subprocess.check_call(["make", "-C", _HERE, "ref"])
+
+
+_lib = None
+_ref = None
+
+_u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        L.yko_float2half_rn.restype = C.c_uint16
+        L.yko_float2half_rn.argtypes = [C.c_float]
+        L.yko_half2float.restype = C.c_float
+        L.yko_half2float.argtypes = [C.c_uint16]
+        L.yko_float2half_array.restype = None
+        L.yko_float2half_array.argtypes = [_f32p, _u16p, C.c_size_t]
+        L.yko_half2float_array.restype = None
+        L.yko_half2float_array.argtypes = [_u16p, _f32p, C.c_size_t]
+        L.yko_pack_tsdf.restype = C.c_uint32
+        L.yko_pack_tsdf.argtypes = [C.c_float, C.c_int]
+        L.yko_unpack_tsdf.restype = C.c_float
+        L.yko_unpack_tsdf.argtypes = [C.c_uint32, C.POINTER(C.c_int)]
+        L.yko_compute_dists.restype = None
+        L.yko_compute_dists.argtypes = [_u16p, C.c_size_t, _u16p, C.c_size_t, C.c_int, C.c_int,
+                                        C.c_float, C.c_float, C.c_float, C.c_float]
+        L.yko_clear_volume.restype = None
+        L.yko_clear_volume.argtypes = [_u32p, C.c_size_t]
+        L.yko_integrate.restype = None
+        L.yko_integrate.argtypes = [_u32p, _i32p, C.c_int, C.c_int, _f32p, C.c_float, C.c_int,
+                                    _u16p, C.c_size_t, C.c_int, C.c_int, _f32p, _f32p, _f32p, _u64p, C.c_int]
+        L.yko_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def ref():
+    """The reference's stand-alone-compilable pieces; None when oracle/_ref was never built."""
+    global _ref
+    if _ref is None:
+        if not os.path.exists(_REF):
+            return None
+        R = C.CDLL(_REF)
+        R.yakref_half2float.restype = C.c_float
+        R.yakref_half2float.argtypes = [C.c_uint16]
+        R.yakref_float2half_ctor.restype = C.c_uint16
+        R.yakref_float2half_ctor.argtypes = [C.c_float]
+        R.yakref_pack.restype = C.c_uint32
+        R.yakref_pack.argtypes = [C.c_float, C.c_uint16]
+        R.yakref_unpack.restype = None
+        R.yakref_unpack.argtypes = [C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint16)]
+        for name in ("yakref_edge_flags", "yakref_triangle_table", "yakref_edge_connections"):
+            getattr(R, name).restype = C.POINTER(C.c_int)
+        _ref = R
+    return _ref
+
+
+# ----------------------------------------------------------------------------------------------
+def float2half(values):
+    v = np.ascontiguousarray(values, dtype=np.float32).ravel()
+    out = np.empty(v.size, dtype=np.uint16)
+    lib().yko_float2half_array(v, out, v.size)
+    return out.reshape(np.shape(values))
+
+
+def half2float(bits):
+    b = np.ascontiguousarray(bits, dtype=np.uint16).ravel()
+    out = np.empty(b.size, dtype=np.float32)
+    lib().yko_half2float_array(b, out, b.size)
+    return out.reshape(np.shape(bits))
+
+
+def compute_dists(depth, intr):
+    """depth: (rows, cols) uint16 mm -> (rows, cols) uint16 half bits (ray length, metres)."""
+    depth = np.ascontiguousarray(depth, dtype=np.uint16)
+    rows, cols = depth.shape
+    out = np.empty_like(depth)
+    fx, fy, cx, cy = (float(v) for v in intr)
+    lib().yko_compute_dists(depth, cols * 2, out, cols * 2, rows, cols, fx, fy, cx, cy)
+    return out
+
+
+def integrate(slab, dims, voxel_size, trunc_dist, max_weight, dists, R, t, intr, z0=0, z1=None, nthreads=1):
+    """In-place update of `slab` ((z1-z0)*Y*X uint32, C order z,y,x).  Returns (visited, updated)."""
+    dims = np.ascontiguousarray(dims, dtype=np.int32)
+    if z1 is None:
+        z1 = int(dims[2])
+    assert slab.dtype == np.uint32 and slab.flags.c_contiguous
+    assert slab.size == (z1 - z0) * int(dims[0]) * int(dims[1])
+    dists = np.ascontiguousarray(dists, dtype=np.uint16)
+    rows, cols = dists.shape
+    stats = np.zeros(2, dtype=np.uint64)
+    lib().yko_integrate(
+        slab.reshape(-1), dims, int(z0), int(z1), np.ascontiguousarray(voxel_size, dtype=np.float32),
+        float(trunc_dist), int(max_weight), dists, cols * 2, rows, cols,
+        np.ascontiguousarray(R, dtype=np.float32).reshape(-1), np.ascontiguousarray(t, dtype=np.float32),
+        np.ascontiguousarray(intr, dtype=np.float32), stats, int(nthreads))
+    return int(stats[0]), int(stats[1])
+
+
+def max_threads():
+    return int(lib().yko_max_threads())

@@ -1,0 +1,269 @@
+/*
+ * yak_oracle.c -- scalar CPU restatement of the Yak TSDF hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see yak_oracle.h).  PARITY UNPINNED for integrate /
+ * compute_dists: the reference has no test or golden vector for them.
+ *
+ * Build: gcc -std=c11 -O2 -ffp-contract=off -fno-fast-math -fopenmp (oracle/Makefile).
+ * -ffp-contract=off matters: every fused multiply-add below is written as fmaf()
+ * exactly where the CUDA source has __fmaf_rn, and nowhere else.
+ *
+ * CUDA intrinsic -> C mapping used throughout:
+ *   __fmaf_rn -> fmaf          __fsqrt_rn / sqrtf -> sqrtf (correctly rounded)
+ *   __fdividef -> IEEE '/'     __float2half[_rn] -> yko_float2half_rn (RNE)
+ *   tex2D point fetch, unnormalised coords -> texel (floor(x), floor(y))
+ *
+ * Citations are relative to /root/reference/yak/.
+ */
+#include "yak_oracle.h"
+
+#include <math.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * IEEE binary16 <-> binary32.  cuda_fp16's __float2half is round-to-nearest-even;
+ * __half2float is exact.  (The reference's vendored half.hpp truncates on
+ * float->half, half.hpp:214-215, so it is NOT used to produce voxels.)
+ * ------------------------------------------------------------------------------------------ */
+uint16_t yko_float2half_rn(float f)
+{
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  const uint32_t abs = u & 0x7fffffffu;
+
+  if (abs >= 0x7f800000u) /* inf / nan */
+    return (uint16_t)(sign | 0x7c00u | (abs > 0x7f800000u ? (0x0200u | ((abs >> 13) & 0x3ffu)) : 0u));
+  if (abs >= 0x477ff000u) /* >= 65520 rounds to inf */
+    return (uint16_t)(sign | 0x7c00u);
+  if (abs < 0x33000001u) /* <= 2^-25 rounds to zero (tie at exactly 2^-25 goes to even = 0) */
+    return (uint16_t)sign;
+
+  const int exp = (int)(abs >> 23); /* biased fp32 exponent */
+  uint32_t mant = abs & 0x7fffffu;
+  uint32_t half;
+  if (exp >= 113)
+  { /* normal half: rebias 127 -> 15, drop 13 mantissa bits with RNE */
+    half = ((uint32_t)(exp - 112) << 10) | (mant >> 13);
+    const uint32_t rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1u)))
+      ++half; /* carry may roll into the exponent: still the right encoding */
+  }
+  else
+  { /* subnormal half: value = mant24 * 2^(exp-150), result unit = 2^-24 */
+    mant |= 0x800000u;
+    const int shift = 126 - exp; /* 14..24 */
+    half = mant >> shift;
+    const uint32_t rem = mant & ((1u << shift) - 1u);
+    const uint32_t halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (half & 1u)))
+      ++half;
+  }
+  return (uint16_t)(sign | half);
+}
+
+float yko_half2float(uint16_t h)
+{
+  const uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+  const uint32_t exp = (h >> 10) & 0x1fu;
+  uint32_t mant = h & 0x3ffu;
+  uint32_t u;
+  if (exp == 0)
+  {
+    if (mant == 0)
+      u = sign;
+    else
+    { /* subnormal: normalise */
+      int e = -1;
+      do
+      {
+        ++e;
+        mant <<= 1;
+      } while (!(mant & 0x400u));
+      u = sign | ((uint32_t)(112 - e) << 23) | ((mant & 0x3ffu) << 13);
+    }
+  }
+  else if (exp == 31)
+    u = sign | 0x7f800000u | (mant << 13);
+  else
+    u = sign | ((exp + 112u) << 23) | (mant << 13);
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+void yko_float2half_array(const float* in, uint16_t* out, size_t n)
+{
+  for (size_t i = 0; i < n; ++i)
+    out[i] = yko_float2half_rn(in[i]);
+}
+
+void yko_half2float_array(const uint16_t* in, float* out, size_t n)
+{
+  for (size_t i = 0; i < n; ++i)
+    out[i] = yko_half2float(in[i]);
+}
+
+/* device.hpp:69-81 (the __CUDA_ARCH__ >= 500 branch: short2, so the weight is a SIGNED 16-bit
+ * lane; with weights in [0, 32767] this is identical to the ushort2 branch :83-96).
+ * Little-endian: bytes 0-1 = half tsdf, bytes 2-3 = weight, the same word layout as
+ * TSDFContainer::unpack (tsdf_container.h:45-49) and the test's pack() (test/marching_cubes_tests.cpp:46-50). */
+uint32_t yko_pack_tsdf(float tsdf, int weight)
+{
+  return (uint32_t)yko_float2half_rn(tsdf) | ((uint32_t)(uint16_t)(int16_t)weight << 16);
+}
+
+float yko_unpack_tsdf(uint32_t voxel, int* weight)
+{
+  if (weight)
+    *weight = (int)(int16_t)(uint16_t)(voxel >> 16);
+  return yko_half2float((uint16_t)(voxel & 0xffffu));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * imgproc.cu:259-283.  finv = 1/f is formed on the host (:281); per pixel
+ *   xl = (x - cx) * finvx; yl = (y - cy) * finvy; lambda = sqrtf(xl*xl + yl*yl + 1)
+ *   dists(y,x) = half_rn( depth(y,x) * lambda * 0.001f )
+ * evaluated left to right in fp32.  No FMA contraction here (C semantics of the source;
+ * nvcc's default -fmad could fuse xl*xl + yl*yl -- unpinned, documented in DESIGN.md).
+ * The kernel's bounds test uses '||' (:264); for in-range pixels the result is the same.
+ * ------------------------------------------------------------------------------------------ */
+void yko_compute_dists(const uint16_t* depth, size_t depth_pitch_bytes, uint16_t* dists, size_t dists_pitch_bytes,
+                       int rows, int cols, float fx, float fy, float cx, float cy)
+{
+  const float finvx = 1.f / fx, finvy = 1.f / fy;
+  for (int y = 0; y < rows; ++y)
+  {
+    const uint16_t* drow = (const uint16_t*)((const char*)depth + (size_t)y * depth_pitch_bytes);
+    uint16_t* orow = (uint16_t*)((char*)dists + (size_t)y * dists_pitch_bytes);
+    const float yl = ((float)y - cy) * finvy;
+    for (int x = 0; x < cols; ++x)
+    {
+      const float xl = ((float)x - cx) * finvx;
+      const float lambda = sqrtf(xl * xl + yl * yl + 1.f);
+      orow[x] = yko_float2half_rn((float)drow[x] * lambda * 0.001f);
+    }
+  }
+}
+
+/* tsdf_volume.cu:14-27: every voxel <- pack_tsdf(0.f, 0) == 0x00000000 */
+void yko_clear_volume(uint32_t* volume, size_t n_voxels)
+{
+  const uint32_t zero = yko_pack_tsdf(0.f, 0);
+  for (size_t i = 0; i < n_voxels; ++i)
+    volume[i] = zero;
+}
+
+/* temp_utils.hpp:36-39 */
+static inline float dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+  return fmaf(ax, bx, fmaf(ay, by, az * bz));
+}
+
+/* One (x, y) column: tsdf_volume.cu:62-108. */
+static void integrate_column(uint32_t* slab, int x, int y, const int dims[3], int z0, int z1, const float vs[3],
+                             float trunc_dist, float trunc_dist_inv, int max_weight, const uint16_t* dists,
+                             size_t pitch, int rows, int cols, const float R[9], const float t[3],
+                             const float intr[4], uint64_t* visited, uint64_t* updated)
+{
+  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+
+  /* :69  zstep = (R.data[0].z, R.data[1].z, R.data[2].z) * voxel_size.z */
+  const float zsx = R[2] * vs[2], zsy = R[5] * vs[2], zsz = R[8] * vs[2];
+
+  /* :71-72  vx = (x*vsx, y*vsy, 0); vc = vol2cam * vx = R*vx + t   (device.hpp:106-111) */
+  const float vxx = (float)x * vs[0], vxy = (float)y * vs[1], vxz = 0.f;
+  float vcx = dot3(R[0], R[1], R[2], vxx, vxy, vxz) + t[0];
+  float vcy = dot3(R[3], R[4], R[5], vxx, vxy, vxz) + t[1];
+  float vcz = dot3(R[6], R[7], R[8], vxx, vxy, vxz) + t[2];
+
+  const size_t plane = (size_t)dims[0] * (size_t)dims[1];
+  uint32_t* vptr = slab + (size_t)x + (size_t)y * (size_t)dims[0]; /* beg(x,y), device.hpp:33-36 */
+
+  /* :76  for (i = 0; i < dims.z; ++i, vc += zstep, vptr = zstep(vptr)) -- the additions run on
+   * every step, including skipped ones, and from z = 0 even when only [z0,z1) is owned. */
+  for (int i = 0; i < z1; ++i, vcx += zsx, vcy += zsy, vcz += zsz)
+  {
+    if (i < z0)
+      continue;
+    uint32_t* p = vptr + (size_t)(i - z0) * plane;
+    ++*visited;
+
+    /* :89 'vc.z <= 0' is tested after the fetch in the source; tested first here because with
+     * vc.z <= 0 the projection may be NaN/inf.  Both orders 'continue' for exactly the same voxels. */
+    if (vcz <= 0.f)
+      continue;
+
+    /* :78  coo = proj(vc)   device.hpp:46-52 */
+    const float coox = fmaf(fx, vcx / vcz, cx);
+    const float cooy = fmaf(fy, vcy / vcz, cy);
+
+    /* :83 */
+    if (coox < 0.f || cooy < 0.f || coox >= (float)cols || cooy >= (float)rows)
+      continue;
+
+    /* :87  point-filtered, unnormalised texture fetch of a half texel */
+    const int px = (int)floorf(coox), py = (int)floorf(cooy);
+    const float Dp = yko_half2float(((const uint16_t*)((const char*)dists + (size_t)py * pitch))[px]);
+
+    /* :89 */
+    if (Dp == 0.f)
+      continue;
+
+    /* :92 */
+    const float sdf = Dp - sqrtf(dot3(vcx, vcy, vcz, vcx, vcy, vcz));
+
+    /* :94-107 */
+    if (sdf >= -trunc_dist)
+    {
+      const float tsdf = fminf(1.f, sdf * trunc_dist_inv);
+      int weight_prev;
+      const float tsdf_prev = yko_unpack_tsdf(*p, &weight_prev);
+      const float tsdf_new = fmaf(tsdf_prev, (float)weight_prev, tsdf) / (float)(weight_prev + 1);
+      const int weight_new = weight_prev + 1 < max_weight ? weight_prev + 1 : max_weight;
+      *p = yko_pack_tsdf(tsdf_new, weight_new);
+      ++*updated;
+    }
+  }
+}
+
+void yko_integrate(uint32_t* slab, const int dims[3], int z0, int z1, const float voxel_size[3], float trunc_dist,
+                   int max_weight, const uint16_t* dists, size_t dists_pitch_bytes, int rows, int cols,
+                   const float R[9], const float t[3], const float intr[4], uint64_t stats[2], int nthreads)
+{
+  /* tsdf_volume.cu:125 */
+  const float trunc_dist_inv = 1.f / trunc_dist;
+  uint64_t visited = 0, updated = 0;
+  if (z0 < 0)
+    z0 = 0;
+  if (z1 > dims[2])
+    z1 = dims[2];
+
+#ifdef _OPENMP
+  if (nthreads < 1)
+    nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads) reduction(+ : visited, updated)
+#endif
+  for (int y = 0; y < dims[1]; ++y)
+    for (int x = 0; x < dims[0]; ++x)
+      integrate_column(slab, x, y, dims, z0, z1, voxel_size, trunc_dist, trunc_dist_inv, max_weight, dists,
+                       dists_pitch_bytes, rows, cols, R, t, intr, &visited, &updated);
+
+  if (stats)
+  {
+    stats[0] += visited;
+    stats[1] += updated;
+  }
+}
+
+int yko_max_threads(void)
+{
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

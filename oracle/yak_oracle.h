@@ -1,0 +1,69 @@
+/*
+ * yak_oracle.h -- CPU restatement of the Yak / kfusion TSDF hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it, and only as the checker / reported baseline.
+ *
+ * Parity status: the reference holds NO test, fixture or golden vector for
+ * integrate / compute_dists / raycast / ICP, and its
+ * implementation of them is CUDA-only, so it cannot be built here.  For those
+ * functions this oracle is "PARITY UNPINNED": it is a line-by-line scalar
+ * restatement of the cited CUDA sources, reviewed against them, and pinned
+ * only where the reference does hold vectors:
+ *   - voxel wire format (test/marching_cubes_tests.cpp:46-79),
+ *   - half -> float decoding (cross-checked against the reference's vendored
+ *     half.hpp compiled into oracle/_ref, all 65536 codes),
+ *   - marching cubes dipyramid known answer (test/marching_cubes_tests.cpp:86-150).
+ *
+ * All file:line citations are relative to /root/reference/yak/.
+ */
+#ifndef YAK_ORACLE_H_
+#define YAK_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- half precision (cuda_fp16 __float2half[_rn] / __half2float) ---------------- */
+uint16_t yko_float2half_rn(float f);
+float yko_half2float(uint16_t h);
+void yko_float2half_array(const float* in, uint16_t* out, size_t n);
+void yko_half2float_array(const uint16_t* in, float* out, size_t n);
+
+/* ---- voxel wire format: include/yak/kfusion/cuda/device.hpp:68-81 ---------------- */
+uint32_t yko_pack_tsdf(float tsdf, int weight);
+float yko_unpack_tsdf(uint32_t voxel, int* weight);
+
+/* ---- src/cuda/imgproc.cu:259-283 (compute_dists_kernel + launcher) ---------------- */
+void yko_compute_dists(const uint16_t* depth, size_t depth_pitch_bytes, uint16_t* dists, size_t dists_pitch_bytes,
+                       int rows, int cols, float fx, float fy, float cx, float cy);
+
+/* ---- src/cuda/tsdf_volume.cu:14-40 ---------------- */
+void yko_clear_volume(uint32_t* volume, size_t n_voxels);
+
+/*
+ * ---- src/cuda/tsdf_volume.cu:51-140 (TsdfIntegrator + device::integrate) ----
+ *
+ * `slab` points at layer z0 of a volume whose full extent is dims[0..2]; the
+ * layers [z0, z1) are updated.  The camera-space position is accumulated from
+ * z = 0 exactly as the reference does (vc += zstep per step, tsdf_volume.cu:76)
+ * so a slab gives bit-identical voxels to the same layers of a whole-volume run.
+ *
+ * R is row-major (precomp.hpp:15-30), intr = {fx, fy, cx, cy}.
+ * stats (may be NULL): stats[0] += voxels visited, stats[1] += voxels updated.
+ * nthreads <= 1: scalar, single thread.  > 1: OpenMP over y.
+ */
+void yko_integrate(uint32_t* slab, const int dims[3], int z0, int z1, const float voxel_size[3], float trunc_dist,
+                   int max_weight, const uint16_t* dists, size_t dists_pitch_bytes, int rows, int cols,
+                   const float R[9], const float t[3], const float intr[4], uint64_t stats[2], int nthreads);
+
+int yko_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,287 @@
+"""GPU parity tests for the hot path: HIP kernels (through the C ABI) vs the scalar CPU oracle.
+
+Bar (BASELINE.json north_star): voxel weights bit-exact, tsdf within 1 half-precision ulp.
+The kernels use the same IEEE operations in the same order as the oracle, so these tests assert the
+stricter thing first -- identical 32-bit voxel words -- and state the north-star tolerance beside it.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from yak_amd import capi, synth
+
+from gpu_helpers import gpu_compute_dists, gpu_integrate, half_ulp_distance
+
+pytestmark = pytest.mark.gpu
+
+TSDF_TOL_HALF_ULP = 1  # north_star: "tsdf values must match within 1 half-precision ulp"
+
+
+def assert_parity(got, want):
+    assert got.shape == want.shape
+    assert np.array_equal(got >> 16, want >> 16), "voxel weights differ (must be bit-exact)"
+    ulp = half_ulp_distance((got & 0xFFFF).astype(np.uint16), (want & 0xFFFF).astype(np.uint16))
+    assert ulp.max() <= TSDF_TOL_HALF_ULP, "tsdf differs by %d half ulps" % ulp.max()
+    assert np.array_equal(got, want), "%d voxel words differ (within tolerance but not bit-exact)" % np.count_nonzero(
+        got != want)
+
+
+def scene(name, frame=0):
+    if name == "s0":
+        return synth.scene_s0()
+    if name == "s1":
+        return synth.scene_s1()
+    return synth.scene_s2(frame)
+
+
+# ---------------------------------------------------------------------------- compute_dists
+@pytest.mark.parametrize("name,frame", [("s0", 0), ("s1", 0), ("s2", 0), ("s2", 133)])
+def test_compute_dists_bit_exact(gpu_ctx, name, frame):
+    depth, _, _ = scene(name, frame)
+    want = oracle.compute_dists(depth, synth.INTR)
+    assert np.array_equal(gpu_compute_dists(gpu_ctx, depth, synth.INTR), want)
+
+
+def test_compute_dists_random_depth_pitched_and_odd_width(gpu_ctx):
+    rng = np.random.default_rng(3)
+    for rows, cols, pitch_in, pitch_out in [(480, 640, 704, 768), (37, 53, 53, 55), (5, 7, 9, 7), (1, 1, 1, 1)]:
+        depth = rng.integers(0, 65536, size=(rows, cols), dtype=np.uint16)
+        depth[rng.random((rows, cols)) < 0.2] = 0
+        intr = (525.0, 530.0, cols / 2 - 0.25, rows / 2 + 0.125)
+        want = oracle.compute_dists(depth, intr)
+        got = gpu_compute_dists(gpu_ctx, depth, intr, pitch_in, pitch_out)
+        assert np.array_equal(got, want), (rows, cols)
+
+
+# ---------------------------------------------------------------------------- integrate
+@pytest.mark.parametrize("name,frame,n", [("s0", 0, 64), ("s1", 0, 64), ("s1", 0, 128), ("s2", 0, 96),
+                                          ("s2", 77, 128), ("s2", 250, 64)])
+def test_integrate_single_frame_bit_exact(gpu_ctx, name, frame, n):
+    depth, R, t = scene(name, frame)
+    dists = oracle.compute_dists(depth, synth.INTR)
+    dims, vs, tr = synth.volume_geometry(n)
+    want = np.zeros(n ** 3, dtype=np.uint32)
+    _, updated = oracle.integrate(want, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR,
+                                  nthreads=oracle.max_threads())
+    assert updated > 0
+    got = gpu_integrate(gpu_ctx, np.zeros(n ** 3, dtype=np.uint32), dims, vs, tr, synth.MAX_WEIGHT, dists, R, t,
+                        synth.INTR)
+    assert_parity(got, want)
+
+
+def test_integrate_orbit_sequence_accumulates_bit_exact(gpu_ctx):
+    """12 frames of the S2 orbit fused one after another: running averages, mixed weights."""
+    n = 80
+    dims, vs, tr = synth.volume_geometry(n)
+    want = np.zeros(n ** 3, dtype=np.uint32)
+    got = np.zeros(n ** 3, dtype=np.uint32)
+    for frame in range(0, 120, 10):
+        depth, R, t = synth.scene_s2(frame, noise_mm=1.0)
+        dists = oracle.compute_dists(depth, synth.INTR)
+        oracle.integrate(want, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR, nthreads=oracle.max_threads())
+        got = gpu_integrate(gpu_ctx, got, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR)
+        assert_parity(got, want)
+    assert len(np.unique(want >> 16)) > 4
+
+
+def test_integrate_weight_saturation(gpu_ctx):
+    depth, R, t = synth.scene_s1()
+    dists = oracle.compute_dists(depth, synth.INTR)
+    dims, vs, tr = synth.volume_geometry(32)
+    want = np.zeros(32 ** 3, dtype=np.uint32)
+    for _ in range(6):
+        oracle.integrate(want, dims, vs, tr, 4, dists, R, t, synth.INTR)
+    got = gpu_integrate(gpu_ctx, np.zeros(32 ** 3, dtype=np.uint32), dims, vs, tr, 4, dists, R, t, synth.INTR,
+                        frames=6)
+    assert (want >> 16).max() == 4
+    assert_parity(got, want)
+
+
+@pytest.mark.parametrize("dims", [(33, 17, 29), (30, 22, 19), (64, 48, 40), (1, 1, 10), (4, 1, 3), (2, 3, 5)])
+def test_integrate_ragged_dims_all_vector_widths(gpu_ctx, dims):
+    """X % 4 == 0 takes the 16-byte path, X % 2 == 0 the 8-byte path, odd X the scalar path."""
+    depth, R, t = synth.scene_s2(40)
+    dists = oracle.compute_dists(depth, synth.INTR)
+    _, vs, tr = synth.volume_geometry(dims)
+    n = dims[0] * dims[1] * dims[2]
+    want = np.zeros(n, dtype=np.uint32)
+    oracle.integrate(want, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR)
+    got = gpu_integrate(gpu_ctx, np.zeros(n, dtype=np.uint32), dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR)
+    assert_parity(got, want)
+
+
+@pytest.mark.parametrize("misalign", [1, 2, 3])
+def test_integrate_unaligned_base_pointer(gpu_ctx, misalign):
+    depth, R, t = synth.scene_s1()
+    dists = oracle.compute_dists(depth, synth.INTR)
+    dims, vs, tr = synth.volume_geometry(32)
+    want = np.zeros(32 ** 3, dtype=np.uint32)
+    oracle.integrate(want, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR)
+    got = gpu_integrate(gpu_ctx, np.zeros(32 ** 3, dtype=np.uint32), dims, vs, tr, synth.MAX_WEIGHT, dists, R, t,
+                        synth.INTR, misalign_words=misalign)
+    assert_parity(got, want)
+
+
+def test_integrate_pitched_dists_image(gpu_ctx):
+    depth, R, t = synth.scene_s2(5)
+    dists = oracle.compute_dists(depth, synth.INTR)
+    dims, vs, tr = synth.volume_geometry(48)
+    want = np.zeros(48 ** 3, dtype=np.uint32)
+    oracle.integrate(want, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR)
+    got = gpu_integrate(gpu_ctx, np.zeros(48 ** 3, dtype=np.uint32), dims, vs, tr, synth.MAX_WEIGHT, dists, R, t,
+                        synth.INTR, dists_pitch_elems=768)
+    assert_parity(got, want)
+
+
+@pytest.mark.parametrize("z_chunk", [1, 2, 7, 16, 1000])
+def test_integrate_any_z_chunk_gives_the_same_volume(gpu_ctx, z_chunk):
+    """The z decomposition replays the reference's float accumulation, so it must not change a bit."""
+    depth, R, t = synth.scene_s2(60)
+    dists = oracle.compute_dists(depth, synth.INTR)
+    dims, vs, tr = synth.volume_geometry((40, 36, 50))
+    n = 40 * 36 * 50
+    want = np.zeros(n, dtype=np.uint32)
+    oracle.integrate(want, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR)
+    gpu_ctx.set_option("z_chunk", z_chunk)
+    try:
+        got = gpu_integrate(gpu_ctx, np.zeros(n, dtype=np.uint32), dims, vs, tr, synth.MAX_WEIGHT, dists, R, t,
+                            synth.INTR)
+    finally:
+        gpu_ctx.set_option("z_chunk", 0)
+    assert_parity(got, want)
+
+
+def test_integrate_z_slabs_concatenate_to_the_whole_volume(gpu_ctx):
+    """Multi-GPU sharding contract: each rank integrates layers [z0, z1); the concatenation is
+    bit-identical to a single whole-volume integrate (no halo, no exchange)."""
+    depth, R, t = synth.scene_s2(200)
+    dists = oracle.compute_dists(depth, synth.INTR)
+    dims, vs, tr = synth.volume_geometry(64)
+    plane = 64 * 64
+    want = np.zeros(64 ** 3, dtype=np.uint32)
+    oracle.integrate(want, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR, nthreads=oracle.max_threads())
+    parts = []
+    for z0, z1 in [(0, 8), (8, 16), (16, 37), (37, 64)]:
+        slab = gpu_integrate(gpu_ctx, np.zeros(plane * (z1 - z0), dtype=np.uint32), dims, vs, tr, synth.MAX_WEIGHT,
+                             dists, R, t, synth.INTR, z0=z0, z1=z1)
+        parts.append(slab)
+    assert_parity(np.concatenate(parts), want)
+
+
+def test_integrate_nontemporal_switch_does_not_change_results(gpu_ctx):
+    depth, R, t = synth.scene_s1()
+    dists = oracle.compute_dists(depth, synth.INTR)
+    dims, vs, tr = synth.volume_geometry(48)
+    a = gpu_integrate(gpu_ctx, np.zeros(48 ** 3, dtype=np.uint32), dims, vs, tr, 64, dists, R, t, synth.INTR)
+    gpu_ctx.set_option("nontemporal", 0)
+    try:
+        b = gpu_integrate(gpu_ctx, np.zeros(48 ** 3, dtype=np.uint32), dims, vs, tr, 64, dists, R, t, synth.INTR)
+    finally:
+        gpu_ctx.set_option("nontemporal", 1)
+    assert np.array_equal(a, b)
+
+
+def test_integrate_empty_frame_and_camera_behind(gpu_ctx):
+    dims, vs, tr = synth.volume_geometry(32)
+    zero = np.zeros(32 ** 3, dtype=np.uint32)
+    _, R, t = synth.scene_s0()
+    # no returns at all: Dp == 0 everywhere
+    got = gpu_integrate(gpu_ctx, zero, dims, vs, tr, 64, np.zeros((480, 640), dtype=np.uint16), R, t, synth.INTR)
+    assert not got.any()
+    # camera looking away from the volume: vc.z <= 0 everywhere
+    dists = oracle.compute_dists(synth.scene_s0()[0], synth.INTR)
+    got = gpu_integrate(gpu_ctx, zero, dims, vs, tr, 64, dists, R, np.array([-1.5, -1.5, -9.0], dtype=np.float32),
+                        synth.INTR)
+    assert not got.any()
+
+
+def test_golden_fixture_without_the_oracle(gpu_ctx):
+    """Committed vectors (tests/golden/s1_32.npz): the HIP path reproduces them word for word."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "s1_32.npz"))
+    depth, R, t = synth.scene_s1()
+    dists = gpu_compute_dists(gpu_ctx, depth, synth.INTR)
+    dims, vs, tr = synth.volume_geometry(32)
+    f1 = gpu_integrate(gpu_ctx, np.zeros(32 ** 3, dtype=np.uint32), dims, vs, tr, 64, dists, R, t, synth.INTR)
+    assert np.array_equal(f1, g["vol_f1"])
+    f3 = gpu_integrate(gpu_ctx, f1, dims, vs, tr, 64, dists, R, t, synth.INTR, frames=2)
+    assert np.array_equal(f3, g["vol_f3"])
+
+
+def test_clear_volume(gpu_ctx):
+    import torch
+
+    for n, off in [(64 ** 3, 0), (1000, 1), (3, 3), (17, 2)]:
+        store = torch.full((n + 8,), 0x7F7F7F7F, dtype=torch.int32, device="cuda")
+        desc = capi.volume_desc(store[off:].data_ptr(), (n, 1, 1), (0.1, 0.1, 0.1), 0.3, 64)
+        gpu_ctx.clear_volume(desc)
+        torch.cuda.synchronize()
+        host = store.cpu().numpy()
+        assert not host[off:off + n].any()
+        assert np.all(host[:off] == 0x7F7F7F7F) and np.all(host[off + n:] == 0x7F7F7F7F)
+
+
+def test_rejected_arguments_raise(gpu_ctx):
+    import torch
+
+    buf = torch.zeros(64, dtype=torch.int32, device="cuda")
+    img = torch.zeros((4, 4), dtype=torch.int16, device="cuda")
+    R, t = np.eye(3).reshape(-1), (0, 0, 0)
+    ok = capi.volume_desc(buf.data_ptr(), (4, 4, 4), (0.1, 0.1, 0.1), 0.3, 64)
+    gpu_ctx.integrate(ok, img.data_ptr(), 8, 4, 4, R, t, synth.INTR)
+    for bad in [capi.volume_desc(0, (4, 4, 4), (0.1, 0.1, 0.1), 0.3, 64),
+                capi.volume_desc(buf.data_ptr(), (0, 4, 4), (0.1, 0.1, 0.1), 0.3, 64),
+                capi.volume_desc(buf.data_ptr(), (4, 4, 4), (0.1, 0.1, 0.1), 0.3, 64, z0=3, z1=2),
+                capi.volume_desc(buf.data_ptr(), (4, 4, 4), (0.1, 0.1, 0.1), 0.3, 64, z0=0, z1=5),
+                capi.volume_desc(buf.data_ptr(), (4, 4, 4), (0.1, 0.1, 0.1), 0.3, 40000),
+                capi.volume_desc(buf.data_ptr(), (4, 4, 4), (0.1, 0.1, 0.1), 0.0, 64)]:
+        with pytest.raises(capi.YakHipError):
+            gpu_ctx.integrate(bad, img.data_ptr(), 8, 4, 4, R, t, synth.INTR)
+    with pytest.raises(capi.YakHipError):
+        gpu_ctx.integrate(ok, img.data_ptr(), 6, 4, 4, R, t, synth.INTR)  # pitch smaller than a row
+    with pytest.raises(capi.YakHipError):
+        gpu_ctx.integrate(ok, 0, 8, 4, 4, R, t, synth.INTR)
+    torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------------------- full size (512^3)
+def test_full_size_s0_known_answer_and_idempotent_weights(gpu_ctx):
+    """BASELINE config 2 at full size, checked by a size-independent property: in scene S0 every
+    voxel is in view and in front of the wall by more than trunc, so after k frames every voxel is
+    exactly (tsdf 1.0, weight k)."""
+    import torch
+
+    n = 512
+    dims, vs, tr = synth.volume_geometry(n)
+    depth, R, t = synth.scene_s0()
+    dists = gpu_compute_dists(gpu_ctx, depth, synth.INTR)
+    dd = torch.from_numpy(dists.view(np.int16)).cuda()
+    vol = torch.empty(n ** 3, dtype=torch.int32, device="cuda")
+    desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT)
+    gpu_ctx.clear_volume(desc)
+    for k in range(1, 4):
+        gpu_ctx.integrate(desc, dd.data_ptr(), 640 * 2, 480, 640, R.reshape(-1), t, synth.INTR)
+        torch.cuda.synchronize()
+        assert bool((vol == ((k << 16) | 0x3C00)).all()), "frame %d" % k
+
+
+def test_full_size_s1_against_threaded_oracle(gpu_ctx):
+    """512^3, scene S1, one frame: the whole 512 MiB volume compared word for word with the oracle
+    (OpenMP over the box's host cores; a few seconds)."""
+    import torch
+
+    n = 512
+    dims, vs, tr = synth.volume_geometry(n)
+    depth, R, t = synth.scene_s1()
+    dists = oracle.compute_dists(depth, synth.INTR)
+    want = np.zeros(n ** 3, dtype=np.uint32)
+    oracle.integrate(want, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR,
+                     nthreads=min(16, oracle.max_threads()))
+    dd = torch.from_numpy(dists.view(np.int16)).cuda()
+    vol = torch.zeros(n ** 3, dtype=torch.int32, device="cuda")
+    desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT)
+    gpu_ctx.integrate(desc, dd.data_ptr(), 640 * 2, 480, 640, R.reshape(-1), t, synth.INTR)
+    torch.cuda.synchronize()
+    got = vol.cpu().numpy().view(np.uint32)
+    assert_parity(got, want)

@@ -1,0 +1,159 @@
+"""ctypes binding of libyakhip.so (include/yakhip.h) -- the thin Python side of the C ABI.
+
+Used by tests/, bench.py and __graft_entry__.py to drive the HIP kernels with device memory
+owned by torch (plumbing only: tensors supply `data_ptr()` and the current stream).
+There is no CPU fallback: if the library is missing or no GPU is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libyakhip.so")
+
+EXPORTS = [
+    "yakhip_ctx_create", "yakhip_ctx_destroy", "yakhip_ctx_set_stream", "yakhip_ctx_synchronize",
+    "yakhip_device_count", "yakhip_device_name", "yakhip_last_error", "yakhip_ctx_set_option",
+    "yakhip_malloc", "yakhip_malloc_pitch", "yakhip_free", "yakhip_upload", "yakhip_download",
+    "yakhip_upload_2d", "yakhip_download_2d",
+    "yakhip_clear_volume", "yakhip_compute_dists", "yakhip_integrate",
+]
+
+
+class YakHipError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("yakhip error %d: %s" % (code, text))
+        self.code = code
+
+
+class VolumeDesc(C.Structure):
+    """struct yakhip_volume"""
+    _fields_ = [
+        ("data", C.c_void_p),
+        ("dims", C.c_int * 3),
+        ("z0", C.c_int),
+        ("z1", C.c_int),
+        ("voxel_size", C.c_float * 3),
+        ("trunc_dist", C.c_float),
+        ("max_weight", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libyakhip.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libyakhip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C yak_amd/csrc`" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i, fp = C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_float)
+    volp = C.POINTER(VolumeDesc)
+    sigs = {
+        "yakhip_ctx_create": [C.POINTER(vp), i],
+        "yakhip_ctx_destroy": [vp],
+        "yakhip_ctx_set_stream": [vp, vp],
+        "yakhip_ctx_synchronize": [vp],
+        "yakhip_device_count": [C.POINTER(i)],
+        "yakhip_device_name": [i, C.c_char_p, sz],
+        "yakhip_ctx_set_option": [vp, C.c_char_p, i],
+        "yakhip_malloc": [vp, C.POINTER(vp), sz],
+        "yakhip_malloc_pitch": [vp, C.POINTER(vp), C.POINTER(sz), sz, sz],
+        "yakhip_free": [vp, vp],
+        "yakhip_upload": [vp, vp, vp, sz],
+        "yakhip_download": [vp, vp, vp, sz],
+        "yakhip_upload_2d": [vp, vp, sz, vp, sz, sz, sz],
+        "yakhip_download_2d": [vp, vp, sz, vp, sz, sz, sz],
+        "yakhip_clear_volume": [vp, volp],
+        "yakhip_compute_dists": [vp, vp, sz, vp, sz, i, i, fp],
+        "yakhip_integrate": [vp, volp, vp, sz, i, i, fp, fp, fp],
+    }
+    for name, argtypes in sigs.items():
+        fn = getattr(L, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    L.yakhip_last_error.argtypes = []
+    L.yakhip_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _chk(rc):
+    if rc != 0:
+        raise YakHipError(rc, load().yakhip_last_error().decode("utf-8", "replace"))
+
+
+def _f32(values, n):
+    vals = [float(v) for v in values]
+    if len(vals) != n:
+        raise ValueError("expected %d floats, got %d" % (n, len(vals)))
+    return (C.c_float * n)(*vals)
+
+
+def device_count():
+    n = C.c_int(0)
+    _chk(load().yakhip_device_count(C.byref(n)))
+    return n.value
+
+
+class Context:
+    """One GPU, one stream: wraps yakhip_ctx.  By default work goes to torch's current stream so
+    that torch tensors, torch events and these kernels are ordered on the same queue."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        L = load()
+        self._h = C.c_void_p()
+        _chk(L.yakhip_ctx_create(C.byref(self._h), int(device)))
+        self.device = int(device)
+        if use_torch_stream:
+            import torch
+
+            self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            load().yakhip_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, raw_stream):
+        _chk(load().yakhip_ctx_set_stream(self._h, C.c_void_p(raw_stream or 0)))
+
+    def set_option(self, key, value):
+        _chk(load().yakhip_ctx_set_option(self._h, key.encode(), int(value)))
+
+    def synchronize(self):
+        _chk(load().yakhip_ctx_synchronize(self._h))
+
+    # ---- hot path; pointers are raw device addresses (ints) ----
+    def clear_volume(self, vol):
+        _chk(load().yakhip_clear_volume(self._h, C.byref(vol)))
+
+    def compute_dists(self, depth_ptr, depth_pitch, dists_ptr, dists_pitch, rows, cols, intr):
+        _chk(load().yakhip_compute_dists(self._h, C.c_void_p(depth_ptr), depth_pitch, C.c_void_p(dists_ptr),
+                                         dists_pitch, rows, cols, _f32(intr, 4)))
+
+    def integrate(self, vol, dists_ptr, dists_pitch, rows, cols, R, t, intr):
+        _chk(load().yakhip_integrate(self._h, C.byref(vol), C.c_void_p(dists_ptr), dists_pitch, rows, cols,
+                                     _f32(R, 9), _f32(t, 3), _f32(intr, 4)))
+
+
+def volume_desc(data_ptr, dims, voxel_size, trunc_dist, max_weight, z0=0, z1=None):
+    v = VolumeDesc()
+    v.data = data_ptr
+    v.dims[:] = [int(d) for d in dims]
+    v.z0 = int(z0)
+    v.z1 = int(dims[2] if z1 is None else z1)
+    v.voxel_size[:] = [float(s) for s in voxel_size]
+    v.trunc_dist = float(trunc_dist)
+    v.max_weight = int(max_weight)
+    return v

@@ -1,0 +1,353 @@
+// api.hip -- the extern "C" surface declared in include/yakhip.h: argument checking, context,
+// device memory, and dispatch to the kernel launchers.  No kernels here.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "yakhip_internal.h"
+
+namespace yakhip
+{
+static thread_local char g_error[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check(hipError_t e, const char* what)
+{
+  if (e == hipSuccess)
+    return 0;
+  snprintf(g_error, sizeof(g_error), "%s: %s (hipError %d)", what, hipGetErrorString(e), (int)e);
+  return (int)e;
+}
+
+// Makes the context's device current for the calling thread.
+static int enter(const yakhip_ctx* ctx)
+{
+  if (!ctx)
+    return fail(YAKHIP_EINVAL, "null context");
+  return check(hipSetDevice(ctx->device), "hipSetDevice");
+}
+
+static int check_volume(const yakhip_volume* v)
+{
+  if (!v || !v->data)
+    return fail(YAKHIP_EINVAL, "volume: null pointer");
+  if (v->dims[0] <= 0 || v->dims[1] <= 0 || v->dims[2] <= 0)
+    return fail(YAKHIP_EINVAL, "volume: dims must be positive, got %d x %d x %d", v->dims[0], v->dims[1], v->dims[2]);
+  if (v->z0 < 0 || v->z0 >= v->z1 || v->z1 > v->dims[2])
+    return fail(YAKHIP_EINVAL, "volume: slab [%d, %d) is not inside [0, %d)", v->z0, v->z1, v->dims[2]);
+  if ((uintptr_t)v->data % 4 != 0)
+    return fail(YAKHIP_EALIGN, "volume: data pointer must be 4-byte aligned");
+  // in-plane offsets are 32-bit on the device; a slab is addressed with 64-bit offsets
+  if ((uint64_t)v->dims[0] * (uint64_t)v->dims[1] > 0x7fffffffull)
+    return fail(YAKHIP_ERANGE, "volume: one z layer exceeds 2^31 voxels");
+  return 0;
+}
+}  // namespace yakhip
+
+using namespace yakhip;
+
+extern "C" {
+
+const char* yakhip_last_error(void) { return g_error; }
+
+int yakhip_device_count(int* count)
+{
+  if (!count)
+    return fail(YAKHIP_EINVAL, "null count");
+  *count = 0;
+  hipError_t e = hipGetDeviceCount(count);
+  if (e == hipErrorNoDevice)
+  {
+    *count = 0;
+    return 0;
+  }
+  return check(e, "hipGetDeviceCount");
+}
+
+int yakhip_device_name(int device, char* buf, size_t buflen)
+{
+  if (!buf || buflen == 0)
+    return fail(YAKHIP_EINVAL, "null buffer");
+  hipDeviceProp_t prop;
+  YAKHIP_TRY(hipGetDeviceProperties(&prop, device));
+  snprintf(buf, buflen, "%s (%s)", prop.name, prop.gcnArchName);
+  return 0;
+}
+
+int yakhip_ctx_create(yakhip_ctx** out, int device)
+{
+  if (!out)
+    return fail(YAKHIP_EINVAL, "null out pointer");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(YAKHIP_ENOGPU, "no HIP device visible (%s)", hipGetErrorString(e));
+  if (device < 0 || device >= n)
+    return fail(YAKHIP_EINVAL, "device %d out of range [0, %d)", device, n);
+  YAKHIP_TRY(hipSetDevice(device));
+  yakhip_ctx* ctx = new yakhip_ctx();
+  ctx->device = device;
+  ctx->z_chunk = 0;
+  ctx->nontemporal = 1;
+  int rc = check(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+  if (rc != 0)
+  {
+    delete ctx;
+    return rc;
+  }
+  ctx->stream = ctx->own_stream;
+  *out = ctx;
+  return 0;
+}
+
+int yakhip_ctx_destroy(yakhip_ctx* ctx)
+{
+  if (!ctx)
+    return 0;
+  int rc = enter(ctx);
+  if (rc == 0)
+  {
+    rc = check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    int rc2 = check(hipStreamDestroy(ctx->own_stream), "hipStreamDestroy");
+    if (rc == 0)
+      rc = rc2;
+  }
+  delete ctx;
+  return rc;
+}
+
+int yakhip_ctx_set_stream(yakhip_ctx* ctx, void* hip_stream)
+{
+  if (!ctx)
+    return fail(YAKHIP_EINVAL, "null context");
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return 0;
+}
+
+int yakhip_ctx_synchronize(yakhip_ctx* ctx)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
+{
+  if (!ctx || !key)
+    return fail(YAKHIP_EINVAL, "null context or key");
+  if (strcmp(key, "z_chunk") == 0)
+  {
+    if (value < 0)
+      return fail(YAKHIP_EINVAL, "z_chunk must be >= 0");
+    ctx->z_chunk = value;
+    return 0;
+  }
+  if (strcmp(key, "nontemporal") == 0)
+  {
+    ctx->nontemporal = value != 0;
+    return 0;
+  }
+  return fail(YAKHIP_EINVAL, "unknown option '%s'", key);
+}
+
+// ---- device memory ------------------------------------------------------------------------------
+
+int yakhip_malloc(yakhip_ctx* ctx, void** ptr, size_t bytes)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!ptr || bytes == 0)
+    return fail(YAKHIP_EINVAL, "malloc: null out pointer or zero size");
+  *ptr = nullptr;
+  return check(hipMalloc(ptr, bytes), "hipMalloc");
+}
+
+int yakhip_malloc_pitch(yakhip_ctx* ctx, void** ptr, size_t* pitch_bytes, size_t width_bytes, size_t rows)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!ptr || !pitch_bytes || width_bytes == 0 || rows == 0)
+    return fail(YAKHIP_EINVAL, "malloc_pitch: null out pointer or zero extent");
+  // rows padded to 256 bytes: every row start is aligned for 16-byte vector access
+  const size_t pitch = (width_bytes + 255u) & ~(size_t)255u;
+  *ptr = nullptr;
+  rc = check(hipMalloc(ptr, pitch * rows), "hipMalloc");
+  if (rc == 0)
+    *pitch_bytes = pitch;
+  return rc;
+}
+
+int yakhip_free(yakhip_ctx* ctx, void* ptr)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!ptr)
+    return 0;
+  return check(hipFree(ptr), "hipFree");
+}
+
+int yakhip_upload(yakhip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!dst_dev || !src_host)
+    return fail(YAKHIP_EINVAL, "upload: null pointer");
+  if (bytes == 0)
+    return 0;
+  YAKHIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");  // blocking, as device_memory.cpp:129-132
+}
+
+int yakhip_download(yakhip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!dst_host || !src_dev)
+    return fail(YAKHIP_EINVAL, "download: null pointer");
+  if (bytes == 0)
+    return 0;
+  YAKHIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+int yakhip_upload_2d(yakhip_ctx* ctx, void* dst_dev, size_t dst_pitch, const void* src_host, size_t src_pitch,
+                     size_t width_bytes, size_t rows)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!dst_dev || !src_host)
+    return fail(YAKHIP_EINVAL, "upload_2d: null pointer");
+  if (width_bytes > dst_pitch || width_bytes > src_pitch)
+    return fail(YAKHIP_EINVAL, "upload_2d: row width exceeds a pitch");
+  if (width_bytes == 0 || rows == 0)
+    return 0;
+  YAKHIP_TRY(hipMemcpy2DAsync(dst_dev, dst_pitch, src_host, src_pitch, width_bytes, rows, hipMemcpyHostToDevice,
+                              ctx->stream));
+  return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+int yakhip_download_2d(yakhip_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_dev, size_t src_pitch,
+                       size_t width_bytes, size_t rows)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!dst_host || !src_dev)
+    return fail(YAKHIP_EINVAL, "download_2d: null pointer");
+  if (width_bytes > dst_pitch || width_bytes > src_pitch)
+    return fail(YAKHIP_EINVAL, "download_2d: row width exceeds a pitch");
+  if (width_bytes == 0 || rows == 0)
+    return 0;
+  YAKHIP_TRY(hipMemcpy2DAsync(dst_host, dst_pitch, src_dev, src_pitch, width_bytes, rows, hipMemcpyDeviceToHost,
+                              ctx->stream));
+  return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+// ---- hot path -----------------------------------------------------------------------------------
+
+int yakhip_clear_volume(yakhip_ctx* ctx, const yakhip_volume* vol)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_volume(vol)) != 0)
+    return rc;
+  const size_t n = (size_t)vol->dims[0] * (size_t)vol->dims[1] * (size_t)(vol->z1 - vol->z0);
+  return launch_clear(ctx, (uint32_t*)vol->data, n);
+}
+
+static int check_image(const char* who, const void* ptr, size_t pitch, int rows, int cols, size_t elem)
+{
+  if (!ptr)
+    return fail(YAKHIP_EINVAL, "%s: null image pointer", who);
+  if (rows <= 0 || cols <= 0)
+    return fail(YAKHIP_EINVAL, "%s: image must be non-empty, got %d x %d", who, rows, cols);
+  if (pitch < (size_t)cols * elem)
+    return fail(YAKHIP_EINVAL, "%s: pitch %zu smaller than a row (%zu bytes)", who, pitch, (size_t)cols * elem);
+  if (pitch % elem != 0 || (uintptr_t)ptr % elem != 0)
+    return fail(YAKHIP_EALIGN, "%s: pointer and pitch must be multiples of %zu bytes", who, elem);
+  if (pitch > 0xffffffffull)
+    return fail(YAKHIP_ERANGE, "%s: pitch too large", who);
+  return 0;
+}
+
+int yakhip_compute_dists(yakhip_ctx* ctx, const void* depth_dev, size_t depth_pitch, void* dists_dev,
+                         size_t dists_pitch, int rows, int cols, const float intr[4])
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!intr)
+    return fail(YAKHIP_EINVAL, "compute_dists: null intrinsics");
+  if ((rc = check_image("compute_dists(depth)", depth_dev, depth_pitch, rows, cols, 2)) != 0)
+    return rc;
+  if ((rc = check_image("compute_dists(dists)", dists_dev, dists_pitch, rows, cols, 2)) != 0)
+    return rc;
+  if (rows > 65535)
+    return fail(YAKHIP_ERANGE, "compute_dists: more than 65535 rows");
+  return launch_compute_dists(ctx, (const uint8_t*)depth_dev, depth_pitch, (uint8_t*)dists_dev, dists_pitch, rows,
+                              cols, intr[0], intr[1], intr[2], intr[3]);
+}
+
+int yakhip_integrate(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dists_dev, size_t dists_pitch, int rows,
+                     int cols, const float R[9], const float t[3], const float intr[4])
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_volume(vol)) != 0)
+    return rc;
+  if (!R || !t || !intr)
+    return fail(YAKHIP_EINVAL, "integrate: null pose or intrinsics");
+  if ((rc = check_image("integrate(dists)", dists_dev, dists_pitch, rows, cols, 2)) != 0)
+    return rc;
+  if (vol->max_weight < 1 || vol->max_weight > 32767)
+    return fail(YAKHIP_ERANGE, "integrate: max_weight %d outside [1, 32767] (the weight lane is int16)",
+                vol->max_weight);
+  if (!(vol->trunc_dist > 0.f))
+    return fail(YAKHIP_EINVAL, "integrate: trunc_dist must be positive");
+
+  IntegrateParams p;
+  p.vol = (uint32_t*)vol->data;
+  p.dists = (const uint8_t*)dists_dev;
+  p.dists_pitch = (uint32_t)dists_pitch;
+  p.rows = rows;
+  p.cols = cols;
+  p.X = vol->dims[0];
+  p.Y = vol->dims[1];
+  p.z0 = vol->z0;
+  p.z1 = vol->z1;
+  p.z_chunk = 0;
+  p.plane = (uint32_t)vol->dims[0] * (uint32_t)vol->dims[1];
+  p.vsx = vol->voxel_size[0];
+  p.vsy = vol->voxel_size[1];
+  p.vsz = vol->voxel_size[2];
+  p.trunc = vol->trunc_dist;
+  p.trunc_inv = 1.f / vol->trunc_dist;  // tsdf_volume.cu:125, formed on the host
+  p.max_weight = vol->max_weight;
+  memcpy(p.R, R, sizeof(p.R));
+  memcpy(p.t, t, sizeof(p.t));
+  p.fx = intr[0];
+  p.fy = intr[1];
+  p.cx = intr[2];
+  p.cy = intr[3];
+  return launch_integrate(ctx, p);
+}
+
+}  // extern "C"

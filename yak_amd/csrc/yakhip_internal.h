@@ -1,0 +1,74 @@
+// yakhip_internal.h -- shared between the HIP translation units of libyakhip.so (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "yakhip.h"
+
+struct yakhip_ctx
+{
+  int device;
+  hipStream_t own_stream;
+  hipStream_t stream;  // own_stream or a borrowed one
+  int z_chunk;         // 0 = auto
+  int nontemporal;     // volume stream bypasses cache retention
+};
+
+namespace yakhip
+{
+// Records the message for yakhip_last_error() and returns `code`.
+int fail(int code, const char* fmt, ...);
+// hipError -> return code (0 stays 0); records file/line text on failure.
+int check(hipError_t e, const char* what);
+
+#define YAKHIP_TRY(expr)                                   \
+  do                                                       \
+  {                                                        \
+    int _rc = ::yakhip::check((expr), #expr);              \
+    if (_rc != 0)                                          \
+      return _rc;                                          \
+  } while (0)
+
+// Everything the integrate kernel needs, passed by value in the kernarg segment so the
+// pose / intrinsics / sizes live in SGPRs (wave-uniform), not in LDS or VGPRs.
+struct IntegrateParams
+{
+  uint32_t* vol;         // layer z0 of the slab
+  const uint8_t* dists;  // half image, row pitch in bytes
+  uint32_t dists_pitch;
+  int rows, cols;
+  int X, Y;              // in-plane extent
+  int z0, z1;            // owned layers
+  int z_chunk;           // layers walked by one workgroup (grid.y index)
+  uint32_t plane;        // X * Y
+  float vsx, vsy, vsz;
+  float trunc, trunc_inv;
+  int max_weight;
+  float R[9];
+  float t[3];
+  float fx, fy, cx, cy;
+};
+
+int launch_integrate(const yakhip_ctx* ctx, const IntegrateParams& p);
+int launch_clear(const yakhip_ctx* ctx, uint32_t* data, size_t n_voxels);
+int launch_compute_dists(const yakhip_ctx* ctx, const uint8_t* depth, size_t depth_pitch, uint8_t* dists,
+                         size_t dists_pitch, int rows, int cols, float fx, float fy, float cx, float cy);
+
+// ---- device helpers shared by kernels --------------------------------------------------------
+__device__ __forceinline__ float half_bits_to_float(uint32_t bits)
+{
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)bits);  // v_cvt_f32_f16: exact
+}
+
+__device__ __forceinline__ uint32_t float_to_half_bits(float f)
+{
+  return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f);  // v_cvt_f16_f32: round-to-nearest-even
+}
+
+// temp_utils.hpp:36-39 -- the nesting order is part of the result
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+  return __builtin_fmaf(ax, bx, __builtin_fmaf(ay, by, az * bz));
+}
+}  // namespace yakhip
