@@ -61,9 +61,14 @@ __device__ __forceinline__ float half_bits_to_float(uint32_t bits)
   return (float)__builtin_bit_cast(_Float16, (unsigned short)bits);  // v_cvt_f32_f16: exact
 }
 
+// fp32 -> fp16, round-to-nearest-even, of a value that has ALREADY been rounded to fp32
+// (__float2half_rn semantics).  The empty asm hides the producer from instruction selection:
+// without it hipcc folds `(half)(a * b)` into v_fma_mixlo_f16, which rounds the exact product
+// once, straight to fp16 -- measured on gfx950 to differ from mul-then-convert in ~1e-4 of pixels.
 __device__ __forceinline__ uint32_t float_to_half_bits(float f)
 {
-  return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f);  // v_cvt_f16_f32: round-to-nearest-even
+  asm("" : "+v"(f));
+  return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f);  // v_cvt_f16_f32
 }
 
 // temp_utils.hpp:36-39 -- the nesting order is part of the result
