@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--scene", default="s0", choices=["s0", "s1"], help="s1 = sphere+wall (partial updates); N=1 only")
     ap.add_argument("--z-chunk", type=int, default=0)
+    ap.add_argument("--vx", type=int, default=0, help="cap on voxels per lane (tuning)")
+    ap.add_argument("--zu", type=int, default=0, help="layers per loop trip (tuning)")
+    ap.add_argument("--no-nt", action="store_true", help="plain instead of non-temporal volume accesses (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -142,6 +145,12 @@ def main():
     ctx = capi.Context(local_rank)  # launches on torch's current stream
     if args.z_chunk:
         ctx.set_option("z_chunk", args.z_chunk)
+    if args.vx:
+        ctx.set_option("vx", args.vx)
+    if args.zu:
+        ctx.set_option("zu", args.zu)
+    if args.no_nt:
+        ctx.set_option("nontemporal", 0)
     d_depth = torch.from_numpy(depth.view(np.int16)).cuda()
     d_dists = torch.empty_like(d_depth)
     ctx.compute_dists(d_depth.data_ptr(), cols * 2, d_dists.data_ptr(), cols * 2, rows, cols, intr)

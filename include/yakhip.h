@@ -68,8 +68,11 @@ typedef struct yakhip_volume
  * Creates a non-blocking stream owned by the context. */
 int yakhip_ctx_create(yakhip_ctx** out, int device);
 int yakhip_ctx_destroy(yakhip_ctx* ctx);
-/* Borrow a caller-owned hipStream_t (e.g. the host framework's current stream); NULL = back to own. */
+/* Borrow a caller-owned hipStream_t (e.g. the host framework's current stream).  NULL is HIP's
+ * default (null) stream, which is what the reference launches on. */
 int yakhip_ctx_set_stream(yakhip_ctx* ctx, void* hip_stream);
+/* Go back to the context's own non-blocking stream. */
+int yakhip_ctx_use_own_stream(yakhip_ctx* ctx);
 /* Replaces cuda::waitAllDefaultStream (yak/src/kfusion/imgproc.cpp:21) and the
  * cudaDeviceSynchronize at yak/src/cuda/tsdf_volume.cu:139. */
 int yakhip_ctx_synchronize(yakhip_ctx* ctx);
@@ -77,8 +80,10 @@ int yakhip_ctx_synchronize(yakhip_ctx* ctx);
 int yakhip_device_count(int* count);
 int yakhip_device_name(int device, char* buf, size_t buflen);
 const char* yakhip_last_error(void);
-/* Engine knobs that are not part of the reference's API.  Keys: "z_chunk" (layers walked by one
- * workgroup, 0 = auto), "nontemporal" (0/1).  Unknown key -> YAKHIP_EINVAL. */
+/* Engine knobs that are not part of the reference's API (results never depend on them).  Keys:
+ * "z_chunk" (layers walked by one workgroup, 0 = auto), "nontemporal" (0/1), "vx" (cap on voxels per
+ * lane: 0 = widest, 1, 2, 4), "zu" (layers per loop trip: 0 = default, 1, 2, 4).
+ * Unknown key or value -> YAKHIP_EINVAL. */
 int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value);
 
 /* ---- device memory: replaces DeviceMemory / DeviceMemory2D

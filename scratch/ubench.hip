@@ -1,0 +1,87 @@
+// VALU issue-rate microbenchmark for gfx950: cycles per wave-instruction at 1..8 waves/SIMD.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int OP>
+__global__ void k(float* out, int iters, float a, float b)
+{
+  float x0 = threadIdx.x * 1e-3f + a, x1 = x0 + 1.f, x2 = x0 + 2.f, x3 = x0 + 3.f;
+  float x4 = x0 + 4.f, x5 = x0 + 5.f, x6 = x0 + 6.f, x7 = x0 + 7.f;
+  f2 p0 = {x0, x1}, p1 = {x2, x3}, p2 = {x4, x5}, p3 = {x6, x7};
+  f2 pa = {a, a}, pb = {b, b};
+  for (int i = 0; i < iters; ++i)
+  {
+    if (OP == 0) {  // 8 independent v_fma_f32
+      asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                   "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+    } else if (OP == 1) {  // 4 independent v_pk_fma_f32 (8 fmas)
+      asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                   : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pa), "v"(pb));
+    } else if (OP == 2) {  // 8 v_rcp_f32
+      asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+    } else if (OP == 3) {  // 8 v_add_f32
+      asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+    } else if (OP == 4) {  // 4 v_pk_add_f32
+      asm volatile("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
+                   : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pa));
+    } else if (OP == 5) {  // 8 v_cvt_f32_f16 / cndmask style simple op: v_mov
+      asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0\n"
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+    } else if (OP == 6) {  // 8 v_sqrt_f32
+      asm volatile("v_sqrt_f32 %0, %0\n v_sqrt_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_sqrt_f32 %3, %3\n v_sqrt_f32 %4, %4\n v_sqrt_f32 %5, %5\n v_sqrt_f32 %6, %6\n v_sqrt_f32 %7, %7\n"
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+    } else if (OP == 7) {  // 8 v_cmp + cndmask pairs? use v_cmp_lt_f32 to vcc
+      asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %2\n v_cmp_lt_f32 vcc, %2, %3\n v_cmp_lt_f32 vcc, %3, %4\n v_cmp_lt_f32 vcc, %4, %5\n v_cmp_lt_f32 vcc, %5, %6\n v_cmp_lt_f32 vcc, %6, %7\n v_cmp_lt_f32 vcc, %7, %0\n"
+                   :: "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7) : "vcc");
+    } else if (OP == 8) {  // 4 v_pk_mul_f32
+      asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                   : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pa));
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+}
+
+template <int OP>
+int run(const char* name, int instr_per_iter, float* d)
+{
+  const int iters = 20000;
+  for (int wps = 1; wps <= 8; wps *= 2)
+  {
+    // one block of wps*4 waves per CU (256 CUs) -> wps waves per SIMD
+    dim3 grid(256), block(64 * 4 * wps);
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k<OP>, grid, block, 0, 0, d, 100, 1.0001f, 0.5f);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k<OP>, grid, block, 0, 0, d, iters, 1.0001f, 0.5f);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    // ns per wave-instruction per SIMD
+    double total_instr_per_simd = (double)iters * instr_per_iter * wps;
+    printf("%-14s waves/SIMD=%d  %.3f ms  %.3f ns per wave-instr per SIMD (%.2f cycles @2.4GHz)\n", name, wps, ms,
+           ms * 1e6 / total_instr_per_simd, ms * 1e6 / total_instr_per_simd * 2.4);
+  }
+  return 0;
+}
+
+int main()
+{
+  float* d; CHECK(hipMalloc(&d, 256 * 2048 * sizeof(float)));
+  run<0>("v_fma_f32", 8, d);
+  run<1>("v_pk_fma_f32", 4, d);
+  run<3>("v_add_f32", 8, d);
+  run<4>("v_pk_add_f32", 4, d);
+  run<8>("v_pk_mul_f32", 4, d);
+  run<5>("v_mov_b32", 8, d);
+  run<7>("v_cmp_lt_f32", 8, d);
+  run<2>("v_rcp_f32", 8, d);
+  run<6>("v_sqrt_f32", 8, d);
+  return 0;
+}

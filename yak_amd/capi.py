@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libyakhip.so")
 
 EXPORTS = [
-    "yakhip_ctx_create", "yakhip_ctx_destroy", "yakhip_ctx_set_stream", "yakhip_ctx_synchronize",
+    "yakhip_ctx_create", "yakhip_ctx_destroy", "yakhip_ctx_set_stream", "yakhip_ctx_use_own_stream", "yakhip_ctx_synchronize",
     "yakhip_device_count", "yakhip_device_name", "yakhip_last_error", "yakhip_ctx_set_option",
     "yakhip_malloc", "yakhip_malloc_pitch", "yakhip_free", "yakhip_upload", "yakhip_download",
     "yakhip_upload_2d", "yakhip_download_2d",
@@ -57,6 +57,7 @@ def load():
         "yakhip_ctx_create": [C.POINTER(vp), i],
         "yakhip_ctx_destroy": [vp],
         "yakhip_ctx_set_stream": [vp, vp],
+        "yakhip_ctx_use_own_stream": [vp],
         "yakhip_ctx_synchronize": [vp],
         "yakhip_device_count": [C.POINTER(i)],
         "yakhip_device_name": [i, C.c_char_p, sz],

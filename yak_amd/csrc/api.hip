@@ -98,6 +98,10 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->device = device;
   ctx->z_chunk = 0;
   ctx->nontemporal = 1;
+  ctx->force_vx = 0;
+  ctx->zu = 0;
+  ctx->thr = nullptr;
+  ctx->thr_bytes = 0;
   int rc = check(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
   if (rc != 0)
   {
@@ -117,6 +121,8 @@ int yakhip_ctx_destroy(yakhip_ctx* ctx)
   if (rc == 0)
   {
     rc = check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    if (ctx->thr)
+      (void)hipFree(ctx->thr);
     int rc2 = check(hipStreamDestroy(ctx->own_stream), "hipStreamDestroy");
     if (rc == 0)
       rc = rc2;
@@ -129,7 +135,15 @@ int yakhip_ctx_set_stream(yakhip_ctx* ctx, void* hip_stream)
 {
   if (!ctx)
     return fail(YAKHIP_EINVAL, "null context");
-  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  ctx->stream = (hipStream_t)hip_stream;
+  return 0;
+}
+
+int yakhip_ctx_use_own_stream(yakhip_ctx* ctx)
+{
+  if (!ctx)
+    return fail(YAKHIP_EINVAL, "null context");
+  ctx->stream = ctx->own_stream;
   return 0;
 }
 
@@ -155,6 +169,20 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
   if (strcmp(key, "nontemporal") == 0)
   {
     ctx->nontemporal = value != 0;
+    return 0;
+  }
+  if (strcmp(key, "vx") == 0)
+  {
+    if (value != 0 && value != 1 && value != 2 && value != 4)
+      return fail(YAKHIP_EINVAL, "vx must be 0, 1, 2 or 4");
+    ctx->force_vx = value;
+    return 0;
+  }
+  if (strcmp(key, "zu") == 0)
+  {
+    if (value != 0 && value != 1 && value != 2 && value != 4)
+      return fail(YAKHIP_EINVAL, "zu must be 0, 1, 2 or 4");
+    ctx->zu = value;
     return 0;
   }
   return fail(YAKHIP_EINVAL, "unknown option '%s'", key);
@@ -326,6 +354,7 @@ int yakhip_integrate(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dist
   IntegrateParams p;
   p.vol = (uint32_t*)vol->data;
   p.dists = (const uint8_t*)dists_dev;
+  p.thr = nullptr;  // filled by the launcher
   p.dists_pitch = (uint32_t)dists_pitch;
   p.rows = rows;
   p.cols = cols;
@@ -340,6 +369,7 @@ int yakhip_integrate(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dist
   p.vsz = vol->voxel_size[2];
   p.trunc = vol->trunc_dist;
   p.trunc_inv = 1.f / vol->trunc_dist;  // tsdf_volume.cu:125, formed on the host
+  p.trunc_hi = vol->trunc_dist * 0x1.008p+0f;  // 1 + 2^-9
   p.max_weight = vol->max_weight;
   memcpy(p.R, R, sizeof(p.R));
   memcpy(p.t, t, sizeof(p.t));

@@ -1,31 +1,40 @@
 // integrate.hip -- TsdfVolume::integrate for gfx950 (MI355X), hand-written HIP.
 //
 // Replaces kfusion::device::integrate + TsdfIntegrator (reference yak/src/cuda/tsdf_volume.cu:51-140)
-// and clear_volume (:14-40).  Same per-voxel arithmetic, different decomposition:
+// and clear_volume (:14-40).  Same per-voxel results (bit for bit against the scalar oracle),
+// different decomposition:
 //
 //   reference (CUDA)                         here (CDNA4)
 //   ---------------------------------------  ----------------------------------------------------
 //   thread = one (x,y) column, serial         lane = VX (4) consecutive x voxels = one 16-byte
 //   512-step z loop, 4-byte ld/st             global_load/store_dwordx4; a wave64 covers 1 KiB of
 //                                             one x-row run per instruction
-//   grid = 1024 blocks over (x,y)             grid = (plane tiles) x (z chunks): thousands of
-//                                             workgroups, each walking `z_chunk` layers
-//   pose/intrinsics in a by-value struct      the same, but read once into SGPRs (wave-uniform)
-//   dists through a texture reference         plain 2-byte gathers; the 600 KiB image stays in L2
-//   ld/st.global.cs                           non-temporal load/store (the volume is streamed once)
+//   grid = 1024 blocks over (x,y)             grid = (plane tiles) x (z chunks)
+//   pose/intrinsics in a by-value struct      the same, read once into SGPRs (wave-uniform)
+//   dists through a texture reference         per-pixel band thresholds precomputed once per frame
+//                                             (8 B/pixel, L2-resident), half image only in the band
+//   3 approximate divides + sqrt per voxel    1 v_rcp + Markstein divides, no sqrt outside the band
+//   ld/st.global.cs                           non-temporal load/store, next trip's voxels prefetched
 //
-// Bit parity with the scalar oracle: the reference accumulates the camera-space position with
-// one float addition per z step (vc += zstep, tsdf_volume.cu:76), so vc(z) != vc0 + z*zstep in
-// floating point.  A workgroup that starts at layer zs therefore REPLAYS the zs additions
-// (3 VALU per voxel per step, no memory) before its first voxel.  All FMAs are explicit and this
-// file is compiled with -ffp-contract=off; '/' and sqrtf are the correctly rounded forms
-// (-fhip-fp32-correctly-rounded-divide-sqrt), matching the oracle's IEEE arithmetic.
+// The kernel is VALU-issue bound before it is HBM bound on this chip (one wave64 VALU instruction
+// per ~4 cycles per SIMD, measured), so the arithmetic is organised to issue as few instructions
+// per voxel as bit-exactness allows; DESIGN.md ("integrate kernel") has the accounting.
+//
+// Bit parity with the scalar oracle:
+//  * the reference accumulates the camera-space position with one float addition per z step
+//    (vc += zstep, tsdf_volume.cu:76), so vc(z) != vc0 + z*zstep in floating point.  A workgroup that
+//    starts at layer zs REPLAYS the zs additions before its first voxel;
+//  * all FMAs are explicit, the file is compiled with -ffp-contract=off;
+//  * every quotient is the correctly rounded IEEE quotient (see div_by below);
+//  * the square root is only needed, and only evaluated (correctly rounded), inside the truncation
+//    band; outside it two sufficient tests with explicit rounding slack decide the voxel.
 #include "yakhip_internal.h"
 
 namespace yakhip
 {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 template <int VX>
 struct Vec;
@@ -66,36 +75,64 @@ __device__ __forceinline__ void vset<1>(uint32_t& v, int, uint32_t x)
   v = x;
 }
 
-// One voxel's measurement: tsdf_volume.cu:78-96.  Returns true when the voxel takes an update.
-__device__ __forceinline__ bool measure(const IntegrateParams& p, float vcx, float vcy, float vcz, float& tsdf)
+// ---- correctly rounded fp32 division in 3 + 3 instructions -------------------------------------
+// refined_rcp(d) = v_rcp_f32 + one Newton step.  On gfx950 it equals the correctly rounded 1/d for
+// EVERY fp32 mantissa (checked exhaustively on the device: tests/test_division_gpu.py; the
+// arithmetic is exponent-invariant while nothing under/overflows).  With y = RN(1/d) and
+// q0 = RN(n*y), Markstein's theorem gives RN(q0 + (n - d*q0)*y) = RN(n/d): the correctly rounded
+// quotient, i.e. bit-identical to IEEE '/'.  Callers keep d inside [2^-20, 2^20]; numerators so
+// small that the residual would underflow cannot change an observable result here.
+__device__ __forceinline__ float refined_rcp(float d)
 {
-  // :89 tests 'vc.z <= 0' after the fetch; testing it first skips exactly the same voxels and keeps
-  // the projection away from x/0.
+  const float r = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r, 1.f);
+  return __builtin_fmaf(e, r, r);
+}
+
+__device__ __forceinline__ float div_by(float n, float d, float r /* refined_rcp(d) */)
+{
+  const float q = n * r;
+  const float e = __builtin_fmaf(-d, q, n);
+  return __builtin_fmaf(e, r, q);
+}
+
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// 2^-20 <= v <= 2^20 (negative, zero, NaN fail)
+__device__ __forceinline__ bool in_div_range(float v)
+{
+  return (__float_as_uint(v) - 0x35800000u) <= (0x49800000u - 0x35800000u);
+}
+
+__device__ __forceinline__ int floor_to_int(float v)
+{
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(v));  // floor, saturating; no builtin exposes it
+  return r;
+}
+
+// One voxel, every case, exactly as the reference writes it: tsdf_volume.cu:78-96.
+// Used for the voxels the fast path cannot settle (truncation band, denominators outside the
+// Markstein range).  Returns true when the voxel takes an update.
+__device__ __forceinline__ bool measure_exact(const IntegrateParams& p, float vcx, float vcy, float vcz, float& tsdf)
+{
+  // :89 tests 'vc.z <= 0' after the fetch; testing it first skips exactly the same voxels
   if (!(vcz > 0.f))
     return false;
-
-  // Projector, device.hpp:46-52
-  const float coox = __builtin_fmaf(p.fx, vcx / vcz, p.cx);
+  const float coox = __builtin_fmaf(p.fx, vcx / vcz, p.cx);  // Projector, device.hpp:46-52
   const float cooy = __builtin_fmaf(p.fy, vcy / vcz, p.cy);
-
-  // :83
-  if (coox < 0.f || cooy < 0.f || coox >= (float)p.cols || cooy >= (float)p.rows)
+  // :83 (written so that a NaN coordinate is rejected instead of indexing the image)
+  if (!(coox >= 0.f && cooy >= 0.f && coox < (float)p.cols && cooy < (float)p.rows))
     return false;
-
   // :87 point fetch at (floor(coo.x), floor(coo.y)); coo >= 0 here so truncation == floor
-  const int px = (int)coox, py = (int)cooy;
-  const uint16_t hbits = *(const uint16_t*)(p.dists + (size_t)py * p.dists_pitch + (size_t)px * 2u);
-  const float Dp = half_bits_to_float(hbits);
+  const uint32_t px = (uint32_t)(int)coox, py = (uint32_t)(int)cooy;
+  const float Dp = half_bits_to_float(*(const uint16_t*)(p.dists + (py * p.dists_pitch + px * 2u)));
   if (Dp == 0.f)
     return false;
-
-  // :92
-  const float sdf = Dp - __builtin_sqrtf(dot3(vcx, vcy, vcz, vcx, vcy, vcz));
-  if (!(sdf >= -p.trunc))
+  const float sdf = Dp - __builtin_sqrtf(dot3(vcx, vcy, vcz, vcx, vcy, vcz));  // :92
+  if (!(sdf >= -p.trunc))                                                      // :94
     return false;
-
-  // :96
-  tsdf = __builtin_fminf(1.f, sdf * p.trunc_inv);
+  tsdf = __builtin_fminf(1.f, sdf * p.trunc_inv);  // :96
   return true;
 }
 
@@ -104,13 +141,260 @@ __device__ __forceinline__ uint32_t fuse(uint32_t voxel, float tsdf, int max_wei
 {
   const float tsdf_prev = half_bits_to_float(voxel & 0xffffu);
   const int weight_prev = (int)(int16_t)(uint16_t)(voxel >> 16);
-  const float tsdf_new = __builtin_fmaf(tsdf_prev, (float)weight_prev, tsdf) / (float)(weight_prev + 1);
+  const float num = __builtin_fmaf(tsdf_prev, (float)weight_prev, tsdf);
+  const float den = (float)(weight_prev + 1);
+  float tsdf_new;
+  if (weight_prev >= 0)  // den in [1, 32768]
+    tsdf_new = div_by(num, den, refined_rcp(den));
+  else
+    tsdf_new = num / den;  // only reachable from a corrupt volume; same arithmetic as the oracle
   const int weight_new = min(weight_prev + 1, max_weight);
   return float_to_half_bits(tsdf_new) | ((uint32_t)(uint16_t)weight_new << 16);
 }
 
-// VX voxels per lane along x, ZU layers in flight per loop trip.
-template <int VX, int ZU, bool NT>
+// ---- per-pixel band thresholds -------------------------------------------------------------------
+// For a voxel at squared camera distance d2 that sees a pixel with ray length Dp:
+//   d2 <= A2(Dp)  =>  Dp - |vc| >= trunc*(1 + 2^-10)  =>  sdf >= -trunc and fmin(1, sdf/trunc) == 1
+//   d2 >  B2(Dp)  =>  Dp - |vc| <  -trunc             =>  no update
+// with A2 = a*a*(1 - 2^-17), a = fma(Dp, 1 - 2^-20, -trunc*(1 + 2^-9)) (when a > 0), and
+//      B2 = b*b*(1 + 2^-17), b = fma(Dp, 1 + 2^-20,  trunc*(1 + 2^-9)).
+// The slack factors dominate every rounding in forming A2, B2, d2, sqrt and the subtraction, so both
+// tests are sufficient (never wrong); what they leave undecided is a shell ~1.002*trunc thick around
+// the surface, which goes through measure_exact().  Pixels with no return (Dp == 0, tsdf_volume.cu:89)
+// or NaN get A2 = B2 = -1: never "in front", always "behind".  Derivation: DESIGN.md, "Band tests".
+__global__ __launch_bounds__(256) void band_thresholds_kernel(const uint8_t* dists, uint32_t dists_pitch, int rows,
+                                                              int cols, float trunc_hi, f32x2* thr)
+{
+  const int x = (int)(blockIdx.x * 256u + threadIdx.x);
+  const int y = (int)blockIdx.y;
+  if (x >= cols)
+    return;
+  const float Dp = half_bits_to_float(*(const uint16_t*)(dists + (size_t)y * dists_pitch + (size_t)x * 2u));
+  f32x2 out = { -1.f, -1.f };
+  if (Dp != 0.f && Dp == Dp)
+  {
+    const float a = __builtin_fmaf(Dp, 0x1.ffffep-1f, -trunc_hi);
+    if (a > 0.f)
+      out.x = (a * a) * 0x1.fffep-1f;  // 1 - 2^-16 .. conservative (>= the 2^-17 the proof needs)
+    const float b = __builtin_fmaf(Dp, 0x1.00001p+0f, trunc_hi);
+    if (b >= 0.f)
+      out.y = (b * b) * 0x1.0001p+0f;  // 1 + 2^-16
+  }
+  thr[(size_t)y * cols + x] = out;
+}
+
+// ---- the kernel ------------------------------------------------------------------------------------
+// Per-lane predicates are kept as 64-bit wave masks in SGPRs (ballot / inverse ballot): combining
+// them is scalar work, and a rare case anywhere in the wave is one scalar branch.
+typedef unsigned long long mask_t;
+__device__ __forceinline__ mask_t ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+__device__ __forceinline__ bool lanes(mask_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+// Camera-space positions of the VX voxels of one lane at one layer, as voxel pairs for packed math.
+template <int VX>
+struct Pos
+{
+  static constexpr int NP = (VX + 1) / 2;
+  f32x2 x[NP], y[NP], z[NP];
+};
+
+// What one layer's projection stage leaves for its update stage (one loop trip later).
+template <int VX>
+struct Probe
+{
+  f32x2 ab[VX];       // gathered {A2, B2} thresholds of the pixel each voxel sees
+  float d2[VX];       // dot(vc, vc)
+  mask_t inside[VX];  // projects into the image (and vc.z is in the Markstein range)
+  mask_t slow[VX];    // vc.z outside [2^-20, 2^20]: only measure_exact() can decide
+};
+
+// Stage 1 of layer z: project VX voxels, start the threshold gathers.
+template <int VX>
+__device__ __forceinline__ void project(const IntegrateParams& p, const Pos<VX>& c, Probe<VX>& o, f32x2 fx2,
+                                        f32x2 fy2, f32x2 cx2, f32x2 cy2)
+{
+#pragma unroll
+  for (int k = 0; k < Pos<VX>::NP; ++k)
+  {
+    // Projector (device.hpp:46-52) for two voxels at once: correctly rounded vc.xy / vc.z
+    f32x2 r = { __builtin_amdgcn_rcpf(c.z[k].x), __builtin_amdgcn_rcpf(c.z[k].y) };
+    r = pk_fma(pk_fma(-c.z[k], r, f32x2{ 1.f, 1.f }), r, r);
+    f32x2 qx = c.x[k] * r;
+    qx = pk_fma(pk_fma(-c.z[k], qx, c.x[k]), r, qx);
+    f32x2 qy = c.y[k] * r;
+    qy = pk_fma(pk_fma(-c.z[k], qy, c.y[k]), r, qy);
+    const f32x2 coox = pk_fma(fx2, qx, cx2);
+    const f32x2 cooy = pk_fma(fy2, qy, cy2);
+    // dot(vc, vc), temp_utils.hpp:36-39
+    const f32x2 d2 = pk_fma(c.x[k], c.x[k], pk_fma(c.y[k], c.y[k], c.z[k] * c.z[k]));
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+    {
+      const int v = 2 * k + h;
+      if (v >= VX)
+        continue;
+      const mask_t fast = ballot(in_div_range(c.z[k][h]));
+      const uint32_t px = (uint32_t)floor_to_int(coox[h]), py = (uint32_t)floor_to_int(cooy[h]);
+      // :83 -- floor(coo) inside the image <=> 0 <= coo < size
+      const mask_t inside = fast & ballot(px < (uint32_t)p.cols) & ballot(py < (uint32_t)p.rows);
+      const uint32_t idx = lanes(inside) ? __umul24(py, (uint32_t)p.cols) + px : 0u;
+      o.ab[v] = p.thr[idx];
+      o.d2[v] = d2[h];
+      o.inside[v] = inside;
+      o.slow[v] = ~fast;
+    }
+  }
+}
+
+template <int VX>
+__device__ __forceinline__ void advance(const Pos<VX>& from, Pos<VX>& to, f32x2 sx, f32x2 sy, f32x2 sz)
+{
+#pragma unroll
+  for (int k = 0; k < Pos<VX>::NP; ++k)
+  {
+    to.x[k] = from.x[k] + sx;
+    to.y[k] = from.y[k] + sy;
+    to.z[k] = from.z[k] + sz;
+  }
+}
+
+// ---- volume access through a buffer descriptor ------------------------------------------------
+// Every volume load/store of the hot loop is a raw buffer op on a descriptor that covers exactly
+// this workgroup's z-chunk.  The lane part of the address (the voxel group inside the layer) never
+// changes, the layer offset is a scalar (soffset), and a lane that must NOT access memory passes
+// voffset = 2^31 (beyond the descriptor): the hardware range check then returns zeros / drops the store.  So each op
+// is issued unconditionally -- no exec-mask branch, a static count for the compiler's s_waitcnt --
+// and costs no address arithmetic per layer.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+// 2 GiB: past the end of any descriptor the launcher builds (chunks are kept below 2 GiB), and far
+// enough from 2^32 that adding the scalar layer offset cannot wrap back into range.
+constexpr uint32_t kNoAccess = 0x80000000u;
+
+template <int VX, bool NT>
+__device__ __forceinline__ typename Vec<VX>::type buf_load(rsrc_t rs, uint32_t voff, uint32_t soff)
+{
+  constexpr int aux = NT ? 2 : 0;  // bit 1 = nt
+  if constexpr (VX == 4)
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, aux));
+  else if constexpr (VX == 2)
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, aux));
+  else
+    return __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, aux);
+}
+
+template <int VX, bool NT>
+__device__ __forceinline__ void buf_store(typename Vec<VX>::type v, rsrc_t rs, uint32_t voff, uint32_t soff)
+{
+  constexpr int aux = NT ? 2 : 0;
+  if constexpr (VX == 4)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), rs, voff, soff, aux);
+  else if constexpr (VX == 2)
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int, v), rs, voff, soff, aux);
+  else
+    __builtin_amdgcn_raw_buffer_store_b32(v, rs, voff, soff, aux);
+}
+
+// Stage 2 of layer z: settle every voxel, fuse, write back; then fetch the voxels two layers ahead
+// into the same register buffer.
+//   soff        byte offset of this layer inside the chunk's buffer
+//   ahead_ok    the layer two steps on is still inside the chunk
+template <int VX, bool NT>
+__device__ __forceinline__ void update(const IntegrateParams& p, const Pos<VX>& c, const Probe<VX>& pr,
+                                       typename Vec<VX>::type& buf, mask_t& buf_valid, rsrc_t rs, uint32_t voff,
+                                       uint32_t soff, uint32_t layer_bytes, bool live, bool ahead_ok,
+                                       uint32_t max_w_hi)
+{
+  typedef typename Vec<VX>::type vec_t;
+  mask_t hit[VX], unit[VX];
+  float tsdf[VX];
+  mask_t rare_any = 0, hit_any = 0;
+  mask_t rare[VX];
+  const mask_t live_m = live ? ~0ull : 0ull;
+#pragma unroll
+  for (int v = 0; v < VX; ++v)
+  {
+    const mask_t front = pr.inside[v] & ballot(pr.d2[v] <= pr.ab[v].x) & live_m;
+    const mask_t behind = ballot(pr.d2[v] > pr.ab[v].y);
+    hit[v] = front;
+    unit[v] = front;
+    tsdf[v] = 1.f;
+    rare[v] = ((pr.inside[v] & ~front & ~behind) | pr.slow[v]) & live_m;
+    rare_any |= rare[v];
+  }
+  if (rare_any != 0)  // wave-uniform branch
+  {
+    // Masks are wave-wide values: they may only be updated in wave-uniform control flow.  Inside the
+    // per-lane regions below only per-lane variables change; the ballots come after the join.
+    bool exact_hit[VX];
+#pragma unroll
+    for (int v = 0; v < VX; ++v)
+    {
+      exact_hit[v] = false;
+      if (lanes(rare[v]))
+      {
+        float t = 1.f;
+        exact_hit[v] = measure_exact(p, c.x[v / 2][v % 2], c.y[v / 2][v % 2], c.z[v / 2][v % 2], t);
+        tsdf[v] = t;
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VX; ++v)
+    {
+      hit[v] |= ballot(exact_hit[v]);
+      unit[v] |= ballot(exact_hit[v] && tsdf[v] == 1.f);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VX; ++v)
+    hit_any |= hit[v];
+
+  // the reference reads only updated voxels (tsdf_volume.cu:98-100): demand-load what the look-ahead
+  // did not bring (first two layers of a chunk, and lanes whose updates start at this layer)
+  const mask_t need = hit_any & ~buf_valid;
+  if (need != 0)  // wave-uniform, rare after the first trips
+  {
+    const vec_t got = buf_load<VX, NT>(rs, lanes(need) ? voff : kNoAccess, soff);
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): settle here so the hot path keeps its counted waits
+#pragma unroll
+    for (int v = 0; v < VX; ++v)
+      vset<VX>(buf, v, lanes(need) ? vget<VX>(got, v) : vget<VX>(buf, v));
+  }
+
+  vec_t out = buf;
+  mask_t general[VX];
+  mask_t general_any = 0;
+#pragma unroll
+  for (int v = 0; v < VX; ++v)
+  {
+    const uint32_t old = vget<VX>(buf, v);
+    // free space seen again: tsdf_prev == 1.0, weight >= 0, new measurement 1.0
+    //   => (1*w + 1) / (w + 1) == 1 exactly; only the weight moves: min(w + 1, max_weight)
+    const mask_t same = hit[v] & unit[v] & ballot((old & 0x8000ffffu) == 0x00003c00u);
+    const u16x2 bumped = __builtin_bit_cast(u16x2, old) + u16x2{ 0, 1 };
+    const u16x2 capped = __builtin_elementwise_min(bumped, __builtin_bit_cast(u16x2, max_w_hi));
+    vset<VX>(out, v, lanes(same) ? __builtin_bit_cast(uint32_t, capped) : old);
+    general[v] = hit[v] & ~same;
+    general_any |= general[v];
+  }
+  if (general_any != 0)  // wave-uniform
+  {
+#pragma unroll
+    for (int v = 0; v < VX; ++v)
+      if (lanes(general[v]))
+        vset<VX>(out, v, fuse(vget<VX>(buf, v), tsdf[v], p.max_weight));
+  }
+  buf_store<VX, NT>(out, rs, lanes(hit_any) ? voff : kNoAccess, soff);
+
+  // look-ahead: updates are coherent along z, so a lane that updated this layer will very likely
+  // update the layer two steps on (this buffer's next use); fetch it now
+  buf_valid = ahead_ok ? hit_any : 0;
+  buf = buf_load<VX, NT>(rs, lanes(buf_valid) ? voff : kNoAccess, soff + 2u * layer_bytes);
+}
+
+// VX voxels per lane along x.  The z loop is software-pipelined two layers deep with two register
+// sets (A, B): while layer z is being settled and written, layer z+1 is already projected and its
+// threshold gathers are in flight, and the voxels of layers z+1 / z+2 are being fetched.
+template <int VX, bool NT>
 __global__ __launch_bounds__(256) void integrate_kernel(const IntegrateParams p)
 {
   typedef typename Vec<VX>::type vec_t;
@@ -127,102 +411,98 @@ __global__ __launch_bounds__(256) void integrate_kernel(const IntegrateParams p)
 
   // :69
   const float zsx = p.R[2] * p.vsz, zsy = p.R[5] * p.vsz, zsz = p.R[8] * p.vsz;
+  f32x2 sx = { zsx, zsx }, sy = { zsy, zsy }, sz = { zsz, zsz };
+  asm volatile("" : "+v"(sx), "+v"(sy), "+v"(sz));  // keep the splats resident (no per-use rebuild)
 
-  // :71-72
-  float vcx[VX], vcy[VX], vcz[VX];
+  // :71-72 (the lane of a pair that does not exist, VX == 1, shadows voxel 0 and is never stored)
+  Pos<VX> A, B;
   const float vxy = (float)y * p.vsy;
 #pragma unroll
-  for (int v = 0; v < VX; ++v)
+  for (int v = 0; v < 2 * Pos<VX>::NP; ++v)
   {
-    const float vxx = (float)(x0 + v) * p.vsx;
-    vcx[v] = dot3(p.R[0], p.R[1], p.R[2], vxx, vxy, 0.f) + p.t[0];
-    vcy[v] = dot3(p.R[3], p.R[4], p.R[5], vxx, vxy, 0.f) + p.t[1];
-    vcz[v] = dot3(p.R[6], p.R[7], p.R[8], vxx, vxy, 0.f) + p.t[2];
+    const float vxx = (float)(x0 + (v < VX ? v : 0)) * p.vsx;
+    A.x[v / 2][v % 2] = dot3(p.R[0], p.R[1], p.R[2], vxx, vxy, 0.f) + p.t[0];
+    A.y[v / 2][v % 2] = dot3(p.R[3], p.R[4], p.R[5], vxx, vxy, 0.f) + p.t[1];
+    A.z[v / 2][v % 2] = dot3(p.R[6], p.R[7], p.R[8], vxx, vxy, 0.f) + p.t[2];
   }
 
   // Replay the additions the reference performed on layers [0, zs) (tsdf_volume.cu:76).
   for (int i = 0; i < zs; ++i)
+    advance<VX>(A, A, sx, sy, sz);
+
+  const f32x2 fx2 = { p.fx, p.fx }, fy2 = { p.fy, p.fy }, cx2 = { p.cx, p.cx }, cy2 = { p.cy, p.cy };
+  const uint32_t max_w_hi = ((uint32_t)p.max_weight << 16) | 0xffffu;
+
+  // descriptor over this chunk's layers [zs, ze); the launcher keeps it below 2 GiB
+  const uint32_t layer_bytes = p.plane * 4u;
+  const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.vol + (size_t)(zs - p.z0) * p.plane, 0,
+                                                      (uint32_t)(ze - zs) * layer_bytes, 0x00020000);
+  const uint32_t voff = elem * 4u;
+
+  // Prologue, shaped like one steady-state half trip so that the compiler's s_waitcnt counting sees
+  // the same queue at loop entry as on the back edge: [voxel fetch] [threshold gathers] [store]
+  // [voxel fetch].  The first two layers are fetched for every lane (nothing is known about them
+  // yet); the store is a no-op (every lane out of range).
+  Probe<VX> PA, PB;
+  mask_t validA = ~0ull, validB = zs + 1 < ze ? ~0ull : 0ull;
+  vec_t bufA = buf_load<VX, NT>(rs, voff, 0u);
+  __builtin_amdgcn_sched_barrier(0);
+  project<VX>(p, A, PA, fx2, fy2, cx2, cy2);
+  __builtin_amdgcn_sched_barrier(0);
+  buf_store<VX, NT>(bufA, rs, kNoAccess, 0u);
+  vec_t bufB = buf_load<VX, NT>(rs, validB ? voff : kNoAccess, layer_bytes);
+  __builtin_amdgcn_sched_barrier(0);
+  uint32_t soff = 0;
+  for (int z = zs; z < ze; z += 2, soff += 2u * layer_bytes)
   {
-#pragma unroll
-    for (int v = 0; v < VX; ++v)
-    {
-      vcx[v] += zsx;
-      vcy[v] += zsy;
-      vcz[v] += zsz;
-    }
-  }
-
-  uint32_t* ptr = p.vol + (size_t)(zs - p.z0) * p.plane + elem;
-
-  for (int z = zs; z < ze; z += ZU, ptr += (size_t)ZU * p.plane)
-  {
-    float tsdf[ZU][VX];
-    uint32_t hit[ZU];  // bit v set: voxel v of layer z+u takes an update
-
-    // phase 1: measurements for ZU layers (dists gathers in flight together)
-#pragma unroll
-    for (int u = 0; u < ZU; ++u)
-    {
-      hit[u] = 0u;
-#pragma unroll
-      for (int v = 0; v < VX; ++v)
-      {
-        tsdf[u][v] = 0.f;
-        if (z + u < ze && measure(p, vcx[v], vcy[v], vcz[v], tsdf[u][v]))
-          hit[u] |= 1u << v;
-        vcx[v] += zsx;
-        vcy[v] += zsy;
-        vcz[v] += zsz;
-      }
-    }
-
-    // phase 2: fetch the voxel groups that changed (the reference reads only updated voxels, :98-100)
-    vec_t vox[ZU];
-#pragma unroll
-    for (int u = 0; u < ZU; ++u)
-    {
-      if (hit[u])
-      {
-        const vec_t* src = (const vec_t*)(ptr + (size_t)u * p.plane);
-        vox[u] = NT ? __builtin_nontemporal_load(src) : *src;
-      }
-    }
-
-    // phase 3: running average + write back
-#pragma unroll
-    for (int u = 0; u < ZU; ++u)
-    {
-      if (hit[u])
-      {
-        vec_t out = vox[u];
-#pragma unroll
-        for (int v = 0; v < VX; ++v)
-          if (hit[u] & (1u << v))
-            vset<VX>(out, v, fuse(vget<VX>(vox[u], v), tsdf[u][v], p.max_weight));
-        vec_t* dst = (vec_t*)(ptr + (size_t)u * p.plane);
-        if (NT)
-          __builtin_nontemporal_store(out, dst);
-        else
-          *dst = out;
-      }
-    }
+    // layer z lives in set A, layer z+1 in set B.  Projections run one layer ahead and are not
+    // guarded at the chunk end: a projection past ze reads valid threshold texels and is discarded.
+    advance<VX>(A, B, sx, sy, sz);
+    project<VX>(p, B, PB, fx2, fy2, cx2, cy2);
+    update<VX, NT>(p, A, PA, bufA, validA, rs, voff, soff, layer_bytes, true, z + 2 < ze, max_w_hi);
+    advance<VX>(B, A, sx, sy, sz);
+    project<VX>(p, A, PA, fx2, fy2, cx2, cy2);
+    update<VX, NT>(p, B, PB, bufB, validB, rs, voff, soff + layer_bytes, layer_bytes, z + 1 < ze, z + 3 < ze,
+                   max_w_hi);
   }
 }
 
-template <int VX, int ZU>
+template <int VX>
 static int launch_variant(const yakhip_ctx* ctx, const IntegrateParams& p, dim3 grid)
 {
   if (ctx->nontemporal)
-    hipLaunchKernelGGL((integrate_kernel<VX, ZU, true>), grid, dim3(256), 0, ctx->stream, p);
+    hipLaunchKernelGGL((integrate_kernel<VX, true>), grid, dim3(256), 0, ctx->stream, p);
   else
-    hipLaunchKernelGGL((integrate_kernel<VX, ZU, false>), grid, dim3(256), 0, ctx->stream, p);
+    hipLaunchKernelGGL((integrate_kernel<VX, false>), grid, dim3(256), 0, ctx->stream, p);
   return check(hipGetLastError(), "integrate_kernel launch");
 }
 
-int launch_integrate(const yakhip_ctx* ctx, const IntegrateParams& p_in)
+int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in)
 {
   IntegrateParams p = p_in;
   const uintptr_t base = (uintptr_t)p.vol;
+
+  // per-pixel band thresholds (8 B/pixel) in context-owned scratch, rebuilt for every frame
+  const size_t thr_bytes = (size_t)p.rows * (size_t)p.cols * sizeof(f32x2);
+  if (ctx->thr_bytes < thr_bytes)
+  {
+    if (ctx->thr)
+    {
+      YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
+      YAKHIP_TRY(hipFree(ctx->thr));
+      ctx->thr = nullptr;
+      ctx->thr_bytes = 0;
+    }
+    YAKHIP_TRY(hipMalloc(&ctx->thr, thr_bytes));
+    ctx->thr_bytes = thr_bytes;
+  }
+  p.thr = (const f32x2*)ctx->thr;
+  {
+    const dim3 grid((unsigned)((p.cols + 255) / 256), (unsigned)p.rows);
+    hipLaunchKernelGGL(band_thresholds_kernel, grid, dim3(256), 0, ctx->stream, p.dists, p.dists_pitch, p.rows,
+                       p.cols, p.trunc_hi, (f32x2*)ctx->thr);
+    YAKHIP_TRY(hipGetLastError());
+  }
 
   // widest vector the layout allows: rows must not straddle a lane's group and the slab base,
   // every row start and every layer start must be aligned to the vector size
@@ -231,17 +511,19 @@ int launch_integrate(const yakhip_ctx* ctx, const IntegrateParams& p_in)
     vx = 4;
   else if (p.X % 2 == 0 && base % 8 == 0)
     vx = 2;
+  if (ctx->force_vx > 0 && ctx->force_vx < vx)
+    vx = ctx->force_vx;
 
   const uint32_t groups = p.plane / (uint32_t)vx;
   const uint32_t blocks_x = (groups + 255u) / 256u;
   const int layers = p.z1 - p.z0;
 
-  // z_chunk: enough workgroups to fill 256 CUs several times over, but long enough that the
-  // replay of layers [0, zs) stays a small fraction of the chunk's own work.
+  // z_chunk: enough workgroups to keep >= 4 waves on every SIMD, but long enough that the replay
+  // of layers [0, zs) stays a small fraction of the chunk's own work.
   int chunk = ctx->z_chunk;
   if (chunk <= 0)
   {
-    const uint32_t want_blocks = 2048u;
+    const uint32_t want_blocks = 1024u;
     uint32_t nchunks = (want_blocks + blocks_x - 1u) / blocks_x;
     if (nchunks < 1u)
       nchunks = 1u;
@@ -251,7 +533,13 @@ int launch_integrate(const yakhip_ctx* ctx, const IntegrateParams& p_in)
   }
   if (chunk > layers)
     chunk = layers;
-  chunk = (chunk + 1) & ~1;  // whole ZU=2 trips
+  // one buffer descriptor spans a chunk: keep it below 2 GiB (see kNoAccess)
+  const uint64_t layer_bytes = (uint64_t)p.plane * 4u;
+  const uint64_t max_chunk = 0x7fffffffull / layer_bytes;
+  if (max_chunk < 1)
+    return fail(YAKHIP_ERANGE, "integrate: one z layer exceeds 2 GiB");
+  if ((uint64_t)chunk > max_chunk)
+    chunk = (int)max_chunk;
   p.z_chunk = chunk;
   const uint32_t nchunks = (uint32_t)((layers + chunk - 1) / chunk);
   if (nchunks > 65535u)
@@ -261,11 +549,11 @@ int launch_integrate(const yakhip_ctx* ctx, const IntegrateParams& p_in)
   switch (vx)
   {
     case 4:
-      return launch_variant<4, 2>(ctx, p, grid);
+      return launch_variant<4>(ctx, p, grid);
     case 2:
-      return launch_variant<2, 2>(ctx, p, grid);
+      return launch_variant<2>(ctx, p, grid);
     default:
-      return launch_variant<1, 2>(ctx, p, grid);
+      return launch_variant<1>(ctx, p, grid);
   }
 }
 

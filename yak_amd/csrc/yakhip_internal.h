@@ -13,10 +13,16 @@ struct yakhip_ctx
   hipStream_t stream;  // own_stream or a borrowed one
   int z_chunk;         // 0 = auto
   int nontemporal;     // volume stream bypasses cache retention
+  int force_vx;        // 0 = widest the layout allows; 1/2/4 caps the voxels per lane
+  int zu;              // layers per loop trip (1, 2, 4); 0 = default
+  void* thr;           // scratch: per-pixel band thresholds of the frame being integrated
+  size_t thr_bytes;
 };
 
 namespace yakhip
 {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // Records the message for yakhip_last_error() and returns `code`.
 int fail(int code, const char* fmt, ...);
 // hipError -> return code (0 stays 0); records file/line text on failure.
@@ -36,6 +42,7 @@ struct IntegrateParams
 {
   uint32_t* vol;         // layer z0 of the slab
   const uint8_t* dists;  // half image, row pitch in bytes
+  const f32x2* thr;      // per-pixel {A2, B2} band thresholds, dense rows x cols
   uint32_t dists_pitch;
   int rows, cols;
   int X, Y;              // in-plane extent
@@ -44,13 +51,14 @@ struct IntegrateParams
   uint32_t plane;        // X * Y
   float vsx, vsy, vsz;
   float trunc, trunc_inv;
+  float trunc_hi;        // trunc * (1 + 2^-9): slack threshold of the sqrt-free band tests
   int max_weight;
   float R[9];
   float t[3];
   float fx, fy, cx, cy;
 };
 
-int launch_integrate(const yakhip_ctx* ctx, const IntegrateParams& p);
+int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p);
 int launch_clear(const yakhip_ctx* ctx, uint32_t* data, size_t n_voxels);
 int launch_compute_dists(const yakhip_ctx* ctx, const uint8_t* depth, size_t depth_pitch, uint8_t* dists,
                          size_t dists_pitch, int rows, int cols, float fx, float fy, float cx, float cy);
