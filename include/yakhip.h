@@ -82,7 +82,7 @@ int yakhip_device_name(int device, char* buf, size_t buflen);
 const char* yakhip_last_error(void);
 /* Engine knobs that are not part of the reference's API (results never depend on them).  Keys:
  * "z_chunk" (layers walked by one workgroup, 0 = auto), "nontemporal" (0/1), "vx" (cap on voxels per
- * lane: 0 = widest, 1, 2, 4), "zu" (layers per loop trip: 0 = default, 1, 2, 4).
+ * lane: 0 = widest, 1, 2, 4), "group_test" (0/1: coarse culling test of whole voxel runs), "zu" (ignored).
  * Unknown key or value -> YAKHIP_EINVAL. */
 int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value);
 

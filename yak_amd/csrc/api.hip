@@ -100,6 +100,7 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->nontemporal = 1;
   ctx->force_vx = 0;
   ctx->zu = 0;
+  ctx->group_test = 1;
   ctx->thr = nullptr;
   ctx->thr_bytes = 0;
   int rc = check(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
@@ -176,6 +177,11 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
     if (value != 0 && value != 1 && value != 2 && value != 4)
       return fail(YAKHIP_EINVAL, "vx must be 0, 1, 2 or 4");
     ctx->force_vx = value;
+    return 0;
+  }
+  if (strcmp(key, "group_test") == 0)
+  {
+    ctx->group_test = value != 0;
     return 0;
   }
   if (strcmp(key, "zu") == 0)
@@ -354,7 +360,8 @@ int yakhip_integrate(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dist
   IntegrateParams p;
   p.vol = (uint32_t*)vol->data;
   p.dists = (const uint8_t*)dists_dev;
-  p.thr = nullptr;  // filled by the launcher
+  p.thr = nullptr;  // thr, coarse, cw/ch and the grp_* constants are filled by the launcher
+  p.coarse = nullptr;
   p.dists_pitch = (uint32_t)dists_pitch;
   p.rows = rows;
   p.cols = cols;

@@ -28,6 +28,8 @@
 //  * every quotient is the correctly rounded IEEE quotient (see div_by below);
 //  * the square root is only needed, and only evaluated (correctly rounded), inside the truncation
 //    band; outside it two sufficient tests with explicit rounding slack decide the voxel.
+#include <cmath>
+
 #include "yakhip_internal.h"
 
 namespace yakhip
@@ -162,25 +164,63 @@ __device__ __forceinline__ uint32_t fuse(uint32_t voxel, float tsdf, int max_wei
 // tests are sufficient (never wrong); what they leave undecided is a shell ~1.002*trunc thick around
 // the surface, which goes through measure_exact().  Pixels with no return (Dp == 0, tsdf_volume.cu:89)
 // or NaN get A2 = B2 = -1: never "in front", always "behind".  Derivation: DESIGN.md, "Band tests".
-__global__ __launch_bounds__(256) void band_thresholds_kernel(const uint8_t* dists, uint32_t dists_pitch, int rows,
-                                                              int cols, float trunc_hi, f32x2* thr)
+__device__ __forceinline__ f32x2 band_thresholds(float Dp, float trunc_hi)
 {
-  const int x = (int)(blockIdx.x * 256u + threadIdx.x);
-  const int y = (int)blockIdx.y;
-  if (x >= cols)
-    return;
-  const float Dp = half_bits_to_float(*(const uint16_t*)(dists + (size_t)y * dists_pitch + (size_t)x * 2u));
   f32x2 out = { -1.f, -1.f };
   if (Dp != 0.f && Dp == Dp)
   {
     const float a = __builtin_fmaf(Dp, 0x1.ffffep-1f, -trunc_hi);
     if (a > 0.f)
-      out.x = (a * a) * 0x1.fffep-1f;  // 1 - 2^-16 .. conservative (>= the 2^-17 the proof needs)
+      out.x = (a * a) * 0x1.fffep-1f;  // 1 - 2^-16: conservative (the proof needs 2^-17; the rest is
+                                       // spent by the group test, which bounds d2 by its end voxels)
     const float b = __builtin_fmaf(Dp, 0x1.00001p+0f, trunc_hi);
     if (b >= 0.f)
       out.y = (b * b) * 0x1.0001p+0f;  // 1 + 2^-16
   }
-  thr[(size_t)y * cols + x] = out;
+  return out;
+}
+
+// One launch per frame, two jobs (both read only the half ray-distance image):
+//   blocks [0, thr_blocks)   per-pixel {A2, B2}                       -> thr[rows][cols]
+//   blocks [thr_blocks, ..)  coarse[by][bx] = min A2 over the pixel window
+//                            [bk*bx, bk*bx + 2*bk) x [bk*by, bk*by + 2*bk) clipped to the image
+//                            (one wave per cell).  Any pixel box no larger than bk x bk whose low
+//                            corner lies in cell (bx, by) is inside that window.
+__global__ __launch_bounds__(256) void prepass_kernel(const uint8_t* dists, uint32_t dists_pitch, int rows, int cols,
+                                                      float trunc_hi, f32x2* thr, float* coarse, int cw, int ch,
+                                                      int bk, uint32_t thr_blocks_x, uint32_t thr_blocks)
+{
+  if (blockIdx.x < thr_blocks)
+  {
+    const int x = (int)((blockIdx.x % thr_blocks_x) * 256u + threadIdx.x);
+    const int y = (int)(blockIdx.x / thr_blocks_x);
+    if (x >= cols)
+      return;
+    const float Dp = half_bits_to_float(*(const uint16_t*)(dists + (size_t)y * dists_pitch + (size_t)x * 2u));
+    thr[(size_t)y * cols + x] = band_thresholds(Dp, trunc_hi);
+    return;
+  }
+  const int cell = (int)(blockIdx.x - thr_blocks) * 4 + (int)(threadIdx.x >> 6);
+  if (cell >= cw * ch)
+    return;
+  const int lane = (int)(threadIdx.x & 63u);
+  const int bx = cell % cw, by = cell / cw;
+  const int w = 2 * bk;
+  float m = __builtin_inff();
+  for (int i = lane; i < w * w; i += 64)
+  {
+    const int x = bk * bx + i % w, y = bk * by + i / w;
+    if (x < cols && y < rows)
+    {
+      const float Dp = half_bits_to_float(*(const uint16_t*)(dists + (size_t)y * dists_pitch + (size_t)x * 2u));
+      m = __builtin_fminf(m, band_thresholds(Dp, trunc_hi).x);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    m = __builtin_fminf(m, __shfl_xor(m, off));
+  if (lane == 0)
+    coarse[cell] = m;
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------
@@ -191,11 +231,17 @@ __device__ __forceinline__ mask_t ballot(bool b) { return __builtin_amdgcn_ballo
 __device__ __forceinline__ bool lanes(mask_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
 // Camera-space positions of the VX voxels of one lane at one layer, as voxel pairs for packed math.
+// With four voxels the pairs are (v0, v3) and (v1, v2): pair 0 then holds the two ends of the run,
+// which is all the group test needs.
 template <int VX>
 struct Pos
 {
   static constexpr int NP = (VX + 1) / 2;
   f32x2 x[NP], y[NP], z[NP];
+  // voxel index held by half h of pair k (>= VX: the slot shadows voxel 0 and is never stored)
+  static constexpr int voxel(int k, int h) { return VX == 4 ? (k == 0 ? (h == 0 ? 0 : 3) : (h == 0 ? 1 : 2)) : 2 * k + h; }
+  static constexpr int pair_of(int v) { return VX == 4 ? (v == 0 || v == 3 ? 0 : 1) : v / 2; }
+  static constexpr int half_of(int v) { return VX == 4 ? (v == 0 || v == 1 ? 0 : 1) : v % 2; }
 };
 
 // What one layer's projection stage leaves for its update stage (one loop trip later).
@@ -206,6 +252,8 @@ struct Probe
   float d2[VX];       // dot(vc, vc)
   mask_t inside[VX];  // projects into the image (and vc.z is in the Markstein range)
   mask_t slow[VX];    // vc.z outside [2^-20, 2^20]: only measure_exact() can decide
+  mask_t pass;        // lanes whose whole voxel run was settled by the group test (all VX voxels hit, tsdf 1)
+  bool detailed;      // wave-uniform: the per-voxel fields above were produced for this layer
 };
 
 // Stage 1 of layer z: project VX voxels, start the threshold gathers.
@@ -230,7 +278,7 @@ __device__ __forceinline__ void project(const IntegrateParams& p, const Pos<VX>&
 #pragma unroll
     for (int h = 0; h < 2; ++h)
     {
-      const int v = 2 * k + h;
+      const int v = Pos<VX>::voxel(k, h);
       if (v >= VX)
         continue;
       const mask_t fast = ballot(in_div_range(c.z[k][h]));
@@ -244,6 +292,52 @@ __device__ __forceinline__ void project(const IntegrateParams& p, const Pos<VX>&
       o.slow[v] = ~fast;
     }
   }
+}
+
+// ---- group test: settle a lane's whole run of voxels with one coarse lookup ---------------------
+// The four voxels of a lane are collinear in camera space, so their pixels lie in the box spanned
+// by the pixels of the two end voxels, and their squared distances are bounded by the larger of the
+// two ends'.  If that pixel box (grown by a margin that covers every rounding below) lies inside the
+// image, is at most one coarse cell wide, and max(d2_ends) <= the minimum of A2 over the coarse
+// window that contains it, then every voxel of the run is in front of the surface by more than the
+// truncation distance: all four take the update with tsdf == 1 -- the same conclusion the per-voxel
+// path reaches, with approximate (v_rcp, no refinement) projections.  Anything else, anywhere in the
+// wave, sends the wave down the exact per-voxel path.  Derivation and margins: DESIGN.md, "Group test".
+__device__ __forceinline__ mask_t group_test(const IntegrateParams& p, f32x2 x, f32x2 y, f32x2 z,
+                                             const float* coarse_lds, f32x2 fx2, f32x2 fy2, f32x2 cx2, f32x2 cy2)
+{
+  const f32x2 rz = { __builtin_amdgcn_rcpf(z.x), __builtin_amdgcn_rcpf(z.y) };
+  const f32x2 u = pk_fma(fx2, x * rz, cx2);
+  const f32x2 w = pk_fma(fy2, y * rz, cy2);
+  const f32x2 d2 = pk_fma(x, x, pk_fma(y, y, z * z));
+  const float ulo = __builtin_fminf(u.x, u.y), uhi = __builtin_fmaxf(u.x, u.y);
+  const float wlo = __builtin_fminf(w.x, w.y), whi = __builtin_fmaxf(w.x, w.y);
+  const float d2max = __builtin_fmaxf(d2.x, d2.y);
+  const float zmin = __builtin_fminf(z.x, z.y);
+  const mask_t ok = ballot(ulo >= p.grp_margin) & ballot(uhi < p.grp_cols_hi) & ballot(wlo >= p.grp_margin) &
+                    ballot(whi < p.grp_rows_hi) & ballot(uhi - ulo <= p.grp_span) & ballot(whi - wlo <= p.grp_span) &
+                    ballot(zmin >= p.grp_zmin);
+  // coarse cell of the low corner: floor((lo - margin) / bk)
+  const int bx = floor_to_int(__builtin_fmaf(ulo, p.grp_inv_bk, p.grp_bias));
+  const int by = floor_to_int(__builtin_fmaf(wlo, p.grp_inv_bk, p.grp_bias));
+  const uint32_t idx = lanes(ok) ? __umul24((uint32_t)by, (uint32_t)p.cw) + (uint32_t)bx : 0u;
+  return ok & ballot(d2max <= coarse_lds[idx]);
+}
+
+// Stage 1 of one layer: group test first; the exact per-voxel projection only if some lane needs it.
+template <int VX>
+__device__ __forceinline__ void stage1(const IntegrateParams& p, const Pos<VX>& c, Probe<VX>& o,
+                                       const float* coarse_lds, mask_t active, f32x2 fx2, f32x2 fy2, f32x2 cx2,
+                                       f32x2 cy2)
+{
+  mask_t pass = 0;
+  if constexpr (VX == 4)
+    if (p.grp_enable)
+      pass = group_test(p, c.x[0], c.y[0], c.z[0], coarse_lds, fx2, fy2, cx2, cy2);
+  o.detailed = (active & ~pass) != 0;
+  o.pass = o.detailed ? 0 : pass;
+  if (o.detailed)
+    project<VX>(p, c, o, fx2, fy2, cx2, cy2);
 }
 
 template <int VX>
@@ -307,41 +401,52 @@ __device__ __forceinline__ void update(const IntegrateParams& p, const Pos<VX>& 
   typedef typename Vec<VX>::type vec_t;
   mask_t hit[VX], unit[VX];
   float tsdf[VX];
-  mask_t rare_any = 0, hit_any = 0;
-  mask_t rare[VX];
+  mask_t hit_any = 0;
   const mask_t live_m = live ? ~0ull : 0ull;
 #pragma unroll
   for (int v = 0; v < VX; ++v)
   {
-    const mask_t front = pr.inside[v] & ballot(pr.d2[v] <= pr.ab[v].x) & live_m;
-    const mask_t behind = ballot(pr.d2[v] > pr.ab[v].y);
-    hit[v] = front;
-    unit[v] = front;
+    hit[v] = unit[v] = pr.pass & live_m;  // the group test settled the whole run (or nothing, if detailed)
     tsdf[v] = 1.f;
-    rare[v] = ((pr.inside[v] & ~front & ~behind) | pr.slow[v]) & live_m;
-    rare_any |= rare[v];
   }
-  if (rare_any != 0)  // wave-uniform branch
+  if (pr.detailed)  // wave-uniform
   {
-    // Masks are wave-wide values: they may only be updated in wave-uniform control flow.  Inside the
-    // per-lane regions below only per-lane variables change; the ballots come after the join.
-    bool exact_hit[VX];
+    mask_t rare_any = 0;
+    mask_t rare[VX];
 #pragma unroll
     for (int v = 0; v < VX; ++v)
     {
-      exact_hit[v] = false;
-      if (lanes(rare[v]))
-      {
-        float t = 1.f;
-        exact_hit[v] = measure_exact(p, c.x[v / 2][v % 2], c.y[v / 2][v % 2], c.z[v / 2][v % 2], t);
-        tsdf[v] = t;
-      }
+      const mask_t front = pr.inside[v] & ballot(pr.d2[v] <= pr.ab[v].x) & live_m;
+      const mask_t behind = ballot(pr.d2[v] > pr.ab[v].y);
+      hit[v] = front;
+      unit[v] = front;
+      rare[v] = ((pr.inside[v] & ~front & ~behind) | pr.slow[v]) & live_m;
+      rare_any |= rare[v];
     }
-#pragma unroll
-    for (int v = 0; v < VX; ++v)
+    if (rare_any != 0)  // wave-uniform branch
     {
-      hit[v] |= ballot(exact_hit[v]);
-      unit[v] |= ballot(exact_hit[v] && tsdf[v] == 1.f);
+      // Masks are wave-wide values: they may only be updated in wave-uniform control flow.  Inside
+      // the per-lane regions below only per-lane variables change; the ballots come after the join.
+      bool exact_hit[VX];
+#pragma unroll
+      for (int v = 0; v < VX; ++v)
+      {
+        exact_hit[v] = false;
+        if (lanes(rare[v]))
+        {
+          float t = 1.f;
+          exact_hit[v] = measure_exact(p, c.x[Pos<VX>::pair_of(v)][Pos<VX>::half_of(v)],
+                                       c.y[Pos<VX>::pair_of(v)][Pos<VX>::half_of(v)],
+                                       c.z[Pos<VX>::pair_of(v)][Pos<VX>::half_of(v)], t);
+          tsdf[v] = t;
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < VX; ++v)
+      {
+        hit[v] |= ballot(exact_hit[v]);
+        unit[v] |= ballot(exact_hit[v] && tsdf[v] == 1.f);
+      }
     }
   }
 #pragma unroll
@@ -392,16 +497,27 @@ __device__ __forceinline__ void update(const IntegrateParams& p, const Pos<VX>& 
 }
 
 // VX voxels per lane along x.  The z loop is software-pipelined two layers deep with two register
-// sets (A, B): while layer z is being settled and written, layer z+1 is already projected and its
-// threshold gathers are in flight, and the voxels of layers z+1 / z+2 are being fetched.
+// sets (A, B): while layer z is being settled and written, layer z+1 is already tested/projected
+// (its threshold gathers in flight), and the voxels of layers z+1 / z+2 are being fetched.
 template <int VX, bool NT>
-__global__ __launch_bounds__(256) void integrate_kernel(const IntegrateParams p)
+__global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams p)
 {
   typedef typename Vec<VX>::type vec_t;
+  extern __shared__ __attribute__((aligned(16))) float coarse_lds[];
+
+  // the coarse threshold image (a few KiB) is read once per workgroup into LDS
+  if (VX == 4 && p.grp_enable)
+  {
+    const int n = p.cw * p.ch;
+    for (int i = (int)threadIdx.x; i < n; i += 256)
+      coarse_lds[i] = p.coarse[i];
+    __syncthreads();
+  }
 
   const uint32_t group = blockIdx.x * 256u + threadIdx.x;  // VX-voxel group inside one z layer
   if (group >= p.plane / VX)
     return;
+  const mask_t active = ballot(true);
   const uint32_t elem = group * VX;  // x + y*X of the first voxel; X % VX == 0 so no row straddle
   const int y = (int)(elem / (uint32_t)p.X);
   const int x0 = (int)(elem - (uint32_t)y * (uint32_t)p.X);
@@ -414,17 +530,20 @@ __global__ __launch_bounds__(256) void integrate_kernel(const IntegrateParams p)
   f32x2 sx = { zsx, zsx }, sy = { zsy, zsy }, sz = { zsz, zsz };
   asm volatile("" : "+v"(sx), "+v"(sy), "+v"(sz));  // keep the splats resident (no per-use rebuild)
 
-  // :71-72 (the lane of a pair that does not exist, VX == 1, shadows voxel 0 and is never stored)
+  // :71-72 (a pair slot that holds no voxel, VX == 1, shadows voxel 0 and is never stored)
   Pos<VX> A, B;
   const float vxy = (float)y * p.vsy;
 #pragma unroll
-  for (int v = 0; v < 2 * Pos<VX>::NP; ++v)
-  {
-    const float vxx = (float)(x0 + (v < VX ? v : 0)) * p.vsx;
-    A.x[v / 2][v % 2] = dot3(p.R[0], p.R[1], p.R[2], vxx, vxy, 0.f) + p.t[0];
-    A.y[v / 2][v % 2] = dot3(p.R[3], p.R[4], p.R[5], vxx, vxy, 0.f) + p.t[1];
-    A.z[v / 2][v % 2] = dot3(p.R[6], p.R[7], p.R[8], vxx, vxy, 0.f) + p.t[2];
-  }
+  for (int k = 0; k < Pos<VX>::NP; ++k)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+    {
+      const int v = Pos<VX>::voxel(k, h);
+      const float vxx = (float)(x0 + (v < VX ? v : 0)) * p.vsx;
+      A.x[k][h] = dot3(p.R[0], p.R[1], p.R[2], vxx, vxy, 0.f) + p.t[0];
+      A.y[k][h] = dot3(p.R[3], p.R[4], p.R[5], vxx, vxy, 0.f) + p.t[1];
+      A.z[k][h] = dot3(p.R[6], p.R[7], p.R[8], vxx, vxy, 0.f) + p.t[2];
+    }
 
   // Replay the additions the reference performed on layers [0, zs) (tsdf_volume.cu:76).
   for (int i = 0; i < zs; ++i)
@@ -440,14 +559,14 @@ __global__ __launch_bounds__(256) void integrate_kernel(const IntegrateParams p)
   const uint32_t voff = elem * 4u;
 
   // Prologue, shaped like one steady-state half trip so that the compiler's s_waitcnt counting sees
-  // the same queue at loop entry as on the back edge: [voxel fetch] [threshold gathers] [store]
-  // [voxel fetch].  The first two layers are fetched for every lane (nothing is known about them
-  // yet); the store is a no-op (every lane out of range).
+  // the same queue at loop entry as on the back edge: [voxel fetch] [stage 1] [store] [voxel fetch].
+  // The first two layers are fetched for every lane (nothing is known about them yet); the store is
+  // a no-op (every lane out of range).
   Probe<VX> PA, PB;
   mask_t validA = ~0ull, validB = zs + 1 < ze ? ~0ull : 0ull;
   vec_t bufA = buf_load<VX, NT>(rs, voff, 0u);
   __builtin_amdgcn_sched_barrier(0);
-  project<VX>(p, A, PA, fx2, fy2, cx2, cy2);
+  stage1<VX>(p, A, PA, coarse_lds, active, fx2, fy2, cx2, cy2);
   __builtin_amdgcn_sched_barrier(0);
   buf_store<VX, NT>(bufA, rs, kNoAccess, 0u);
   vec_t bufB = buf_load<VX, NT>(rs, validB ? voff : kNoAccess, layer_bytes);
@@ -455,13 +574,13 @@ __global__ __launch_bounds__(256) void integrate_kernel(const IntegrateParams p)
   uint32_t soff = 0;
   for (int z = zs; z < ze; z += 2, soff += 2u * layer_bytes)
   {
-    // layer z lives in set A, layer z+1 in set B.  Projections run one layer ahead and are not
-    // guarded at the chunk end: a projection past ze reads valid threshold texels and is discarded.
+    // layer z lives in set A, layer z+1 in set B.  Stage 1 runs one layer ahead and is not guarded at
+    // the chunk end: a projection past ze reads valid threshold texels and is discarded.
     advance<VX>(A, B, sx, sy, sz);
-    project<VX>(p, B, PB, fx2, fy2, cx2, cy2);
+    stage1<VX>(p, B, PB, coarse_lds, active, fx2, fy2, cx2, cy2);
     update<VX, NT>(p, A, PA, bufA, validA, rs, voff, soff, layer_bytes, true, z + 2 < ze, max_w_hi);
     advance<VX>(B, A, sx, sy, sz);
-    project<VX>(p, A, PA, fx2, fy2, cx2, cy2);
+    stage1<VX>(p, A, PA, coarse_lds, active, fx2, fy2, cx2, cy2);
     update<VX, NT>(p, B, PB, bufB, validB, rs, voff, soff + layer_bytes, layer_bytes, z + 1 < ze, z + 3 < ze,
                    max_w_hi);
   }
@@ -470,10 +589,11 @@ __global__ __launch_bounds__(256) void integrate_kernel(const IntegrateParams p)
 template <int VX>
 static int launch_variant(const yakhip_ctx* ctx, const IntegrateParams& p, dim3 grid)
 {
+  const size_t lds = VX == 4 && p.grp_enable ? (size_t)p.cw * p.ch * sizeof(float) : 0;
   if (ctx->nontemporal)
-    hipLaunchKernelGGL((integrate_kernel<VX, true>), grid, dim3(256), 0, ctx->stream, p);
+    hipLaunchKernelGGL((integrate_kernel<VX, true>), grid, dim3(256), lds, ctx->stream, p);
   else
-    hipLaunchKernelGGL((integrate_kernel<VX, false>), grid, dim3(256), 0, ctx->stream, p);
+    hipLaunchKernelGGL((integrate_kernel<VX, false>), grid, dim3(256), lds, ctx->stream, p);
   return check(hipGetLastError(), "integrate_kernel launch");
 }
 
@@ -482,9 +602,16 @@ int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in)
   IntegrateParams p = p_in;
   const uintptr_t base = (uintptr_t)p.vol;
 
-  // per-pixel band thresholds (8 B/pixel) in context-owned scratch, rebuilt for every frame
+  // ---- per-frame prepass into context-owned scratch: per-pixel band thresholds (8 B/pixel) and
+  //      the coarse minima the group test looks up (one float per bk x bk pixel cell) ----
+  int bk = 8;
+  while (((p.cols + bk - 1) / bk) * ((p.rows + bk - 1) / bk) * (int)sizeof(float) > 32768 && bk < 1024)
+    bk *= 2;
+  p.cw = (p.cols + bk - 1) / bk;
+  p.ch = (p.rows + bk - 1) / bk;
   const size_t thr_bytes = (size_t)p.rows * (size_t)p.cols * sizeof(f32x2);
-  if (ctx->thr_bytes < thr_bytes)
+  const size_t coarse_bytes = (size_t)p.cw * p.ch * sizeof(float);
+  if (ctx->thr_bytes < thr_bytes + coarse_bytes)
   {
     if (ctx->thr)
     {
@@ -493,15 +620,46 @@ int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in)
       ctx->thr = nullptr;
       ctx->thr_bytes = 0;
     }
-    YAKHIP_TRY(hipMalloc(&ctx->thr, thr_bytes));
-    ctx->thr_bytes = thr_bytes;
+    YAKHIP_TRY(hipMalloc(&ctx->thr, thr_bytes + coarse_bytes));
+    ctx->thr_bytes = thr_bytes + coarse_bytes;
   }
   p.thr = (const f32x2*)ctx->thr;
+  p.coarse = (const float*)((const char*)ctx->thr + thr_bytes);
   {
-    const dim3 grid((unsigned)((p.cols + 255) / 256), (unsigned)p.rows);
-    hipLaunchKernelGGL(band_thresholds_kernel, grid, dim3(256), 0, ctx->stream, p.dists, p.dists_pitch, p.rows,
-                       p.cols, p.trunc_hi, (f32x2*)ctx->thr);
+    const uint32_t thr_blocks_x = (uint32_t)((p.cols + 255) / 256);
+    const uint32_t thr_blocks = thr_blocks_x * (uint32_t)p.rows;
+    const uint32_t cell_blocks = (uint32_t)((p.cw * p.ch + 3) / 4);
+    hipLaunchKernelGGL(prepass_kernel, dim3(thr_blocks + cell_blocks), dim3(256), 0, ctx->stream, p.dists,
+                       p.dists_pitch, p.rows, p.cols, p.trunc_hi, (f32x2*)ctx->thr, (float*)p.coarse, p.cw, p.ch, bk,
+                       thr_blocks_x, thr_blocks);
     YAKHIP_TRY(hipGetLastError());
+  }
+
+  // ---- group-test constants ("Group test") ----
+  // margin: 1/64 px covers the approximate projections (v_rcp, unrefined: < 2e-3 px inside a 32k px
+  // image) and the deviation of the rounded voxel positions from a straight line, which is at most
+  // f * 2^-23 * P / z px (P = largest |camera coordinate| in the volume); requiring
+  // z >= f * P * 2^-15 keeps that below a quarter of the margin.
+  {
+    const float margin = 1.f / 64.f;
+    float P = 0.f;
+    for (int i = 0; i < 3; ++i)
+    {
+      const float ext = fabsf(p.R[3 * i + 0]) * p.vsx * (float)p.X + fabsf(p.R[3 * i + 1]) * p.vsy * (float)p.Y +
+                        fabsf(p.R[3 * i + 2]) * p.vsz * (float)p.z1 + fabsf(p.t[i]);
+      P = fmaxf(P, ext);
+    }
+    const float f = fmaxf(fabsf(p.fx), fabsf(p.fy));
+    p.grp_margin = margin;
+    p.grp_cols_hi = (float)p.cols - margin;
+    p.grp_rows_hi = (float)p.rows - margin;
+    p.grp_span = (float)bk - 2.f * margin;
+    p.grp_inv_bk = 1.f / (float)bk;
+    p.grp_bias = -margin / (float)bk;
+    p.grp_zmin = fmaxf(f * P * 0x1p-15f, 0x1p-10f);
+    // the test assumes an ordinary pinhole (positive focal lengths, image below 32k px) and finite pose
+    p.grp_enable = ctx->group_test && p.fx > 0.f && p.fy > 0.f && p.cols < 32768 && p.rows < 32768 &&
+                   std::isfinite(P) && std::isfinite(f) && coarse_bytes <= 32768;
   }
 
   // widest vector the layout allows: rows must not straddle a lane's group and the slab base,

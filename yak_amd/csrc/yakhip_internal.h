@@ -14,7 +14,8 @@ struct yakhip_ctx
   int z_chunk;         // 0 = auto
   int nontemporal;     // volume stream bypasses cache retention
   int force_vx;        // 0 = widest the layout allows; 1/2/4 caps the voxels per lane
-  int zu;              // layers per loop trip (1, 2, 4); 0 = default
+  int zu;              // (unused; kept for option compatibility)
+  int group_test;      // coarse group test on (default) / off
   void* thr;           // scratch: per-pixel band thresholds of the frame being integrated
   size_t thr_bytes;
 };
@@ -43,6 +44,10 @@ struct IntegrateParams
   uint32_t* vol;         // layer z0 of the slab
   const uint8_t* dists;  // half image, row pitch in bytes
   const f32x2* thr;      // per-pixel {A2, B2} band thresholds, dense rows x cols
+  const float* coarse;   // coarse minima of A2 (group test), cw x ch cells
+  int cw, ch;
+  int grp_enable;
+  float grp_margin, grp_cols_hi, grp_rows_hi, grp_span, grp_inv_bk, grp_bias, grp_zmin;
   uint32_t dists_pitch;
   int rows, cols;
   int X, Y;              // in-plane extent
