@@ -82,9 +82,22 @@ int yakhip_device_name(int device, char* buf, size_t buflen);
 const char* yakhip_last_error(void);
 /* Engine knobs that are not part of the reference's API (results never depend on them).  Keys:
  * "z_chunk" (layers walked by one workgroup, 0 = auto), "nontemporal" (0/1), "vx" (cap on voxels per
- * lane: 0 = widest, 1, 2, 4), "group_test" (0/1: coarse culling test of whole voxel runs), "zu" (ignored).
+ * lane: 0 = widest, 1, 2, 4), "group_test" (0/1: coarse culling test of whole voxel runs),
+ * "kernel_timing" (0/1, see yakhip_ctx_kernel_time), "zu" (ignored).
  * Unknown key or value -> YAKHIP_EINVAL. */
 int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value);
+/* Measurement aid with no counterpart in the reference (its only timers are the never-invoked
+ * ScopeTime/SampledScopeTime, yak/src/kfusion/core.cpp:236-260).  After
+ * yakhip_ctx_set_option(ctx, "kernel_timing", 1) every integrate kernel launch is bracketed by a
+ * hipEvent pair on the context's stream; this call waits for them, returns the summed device time of
+ * those launches (milliseconds) and their count, and restarts the accumulation. */
+int yakhip_ctx_kernel_time(yakhip_ctx* ctx, double* total_ms, int* launches);
+/* Device self-test with no counterpart in the reference: the integrate kernel replaces IEEE '/' by a
+ * v_rcp_f32 + Newton + Markstein sequence; this checks on the GPU at hand that (a) the refined
+ * reciprocal is the correctly rounded 1/d for all 2^23 mantissas at 8 exponents and (b) the quotient
+ * equals n / d on ~10^9 pseudo-random pairs.  counts = {reciprocals checked, mismatches, quotients
+ * checked, mismatches}; both mismatch counts must be 0 for the kernel's bit-exactness argument. */
+int yakhip_selftest_division(yakhip_ctx* ctx, unsigned long long counts[4]);
 
 /* ---- device memory: replaces DeviceMemory / DeviceMemory2D
  *      (yak/src/kfusion/device_memory.cpp:85-103 create, :129-138 upload/download,

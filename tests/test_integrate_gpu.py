@@ -285,3 +285,70 @@ def test_full_size_s1_against_threaded_oracle(gpu_ctx):
     torch.cuda.synchronize()
     got = vol.cpu().numpy().view(np.uint32)
     assert_parity(got, want)
+
+
+# ---------------------------------------------------------------------------- randomized poses
+def _random_pose(rng, inside):
+    """Camera somewhere around (or inside) the 3 m cube, looking roughly at it, with roll."""
+    centre = np.array([1.5, 1.5, 1.5])
+    if inside:
+        eye = centre + rng.uniform(-1.2, 1.2, 3)
+        target = eye + rng.normal(size=3)
+    else:
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        eye = centre + d * rng.uniform(2.2, 6.0)
+        target = centre + rng.uniform(-0.8, 0.8, 3)
+    up = rng.normal(size=3)
+    R_c2v, eye = synth.look_at(eye, target, up=up / np.linalg.norm(up))
+    return R_c2v, eye
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_integrate_random_poses_scenes_and_intrinsics(gpu_ctx, seed):
+    """Cameras outside, inside and grazing the volume, rolled, with odd intrinsics and image sizes:
+    exercises the group test's margins (image borders, depth edges, near plane), the band path and the
+    exact fallbacks against the oracle, three frames deep."""
+    rng = np.random.default_rng(1000 + seed)
+    rows, cols = [(480, 640), (240, 320), (97, 131), (600, 800)][seed % 4]
+    f = cols * rng.uniform(0.6, 1.6)
+    intr = (float(f), float(f * rng.uniform(0.9, 1.1)), float(cols / 2 + rng.uniform(-20, 20)),
+            float(rows / 2 + rng.uniform(-20, 20)))
+    n = [64, 48, 80, 56][seed % 4]
+    dims, vs, tr = synth.volume_geometry((n, n - 8, n + 4))
+    nvox = dims[0] * dims[1] * dims[2]
+    want = np.zeros(nvox, dtype=np.uint32)
+    got = np.zeros(nvox, dtype=np.uint32)
+    total = 0
+    for frame in range(3):
+        R_c2v, eye = _random_pose(rng, inside=(seed % 3 == 2))
+        spheres = [(rng.uniform(0.5, 2.5, 3), float(rng.uniform(0.2, 0.9))) for _ in range(3)]
+        planes = [((0, 0, float(rng.uniform(2.0, 3.5))), (0, 0, 1)), ((0, float(rng.uniform(2.0, 3.2)), 0), (0, 1, 0))]
+        depth = synth.render_depth(R_c2v, eye, planes=planes, spheres=spheres, intr=intr, rows=rows, cols=cols,
+                                   noise_mm=float(seed % 2), seed=seed * 10 + frame)
+        R, t = synth.vol2cam(R_c2v, eye)
+        dists = oracle.compute_dists(depth, intr)
+        _, upd = oracle.integrate(want, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, intr,
+                                  nthreads=oracle.max_threads())
+        total += upd
+        got = gpu_integrate(gpu_ctx, got, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, intr)
+        assert_parity(got, want)
+    assert total > 0
+
+
+def test_integrate_group_test_switch_does_not_change_results(gpu_ctx):
+    depth, R, t = synth.scene_s2(123, noise_mm=1.0)
+    dists = oracle.compute_dists(depth, synth.INTR)
+    dims, vs, tr = synth.volume_geometry(96)
+    a = gpu_integrate(gpu_ctx, np.zeros(96 ** 3, dtype=np.uint32), dims, vs, tr, 64, dists, R, t, synth.INTR, frames=2)
+    gpu_ctx.set_option("group_test", 0)
+    try:
+        b = gpu_integrate(gpu_ctx, np.zeros(96 ** 3, dtype=np.uint32), dims, vs, tr, 64, dists, R, t, synth.INTR,
+                          frames=2)
+    finally:
+        gpu_ctx.set_option("group_test", 1)
+    assert np.array_equal(a, b)
+    want = np.zeros(96 ** 3, dtype=np.uint32)
+    for _ in range(2):
+        oracle.integrate(want, dims, vs, tr, 64, dists, R, t, synth.INTR, nthreads=oracle.max_threads())
+    assert_parity(a, want)

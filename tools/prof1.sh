@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/prof1.sh <tag> [bench args...]
+# usage: tools/prof1.sh <tag> [bench args...]
 set -u
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp

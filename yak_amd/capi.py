@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libyakhip.so")
 EXPORTS = [
     "yakhip_ctx_create", "yakhip_ctx_destroy", "yakhip_ctx_set_stream", "yakhip_ctx_use_own_stream", "yakhip_ctx_synchronize",
     "yakhip_device_count", "yakhip_device_name", "yakhip_last_error", "yakhip_ctx_set_option",
+    "yakhip_ctx_kernel_time", "yakhip_selftest_division",
     "yakhip_malloc", "yakhip_malloc_pitch", "yakhip_free", "yakhip_upload", "yakhip_download",
     "yakhip_upload_2d", "yakhip_download_2d",
     "yakhip_clear_volume", "yakhip_compute_dists", "yakhip_integrate",
@@ -62,6 +63,8 @@ def load():
         "yakhip_device_count": [C.POINTER(i)],
         "yakhip_device_name": [i, C.c_char_p, sz],
         "yakhip_ctx_set_option": [vp, C.c_char_p, i],
+        "yakhip_ctx_kernel_time": [vp, C.POINTER(C.c_double), C.POINTER(i)],
+        "yakhip_selftest_division": [vp, C.POINTER(C.c_ulonglong)],
         "yakhip_malloc": [vp, C.POINTER(vp), sz],
         "yakhip_malloc_pitch": [vp, C.POINTER(vp), C.POINTER(sz), sz, sz],
         "yakhip_free": [vp, vp],
@@ -131,6 +134,17 @@ class Context:
 
     def set_option(self, key, value):
         _chk(load().yakhip_ctx_set_option(self._h, key.encode(), int(value)))
+
+    def kernel_time(self):
+        """(total device ms, launches) of the integrate kernel since kernel_timing was switched on."""
+        ms, n = C.c_double(0.0), C.c_int(0)
+        _chk(load().yakhip_ctx_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def selftest_division(self):
+        out = (C.c_ulonglong * 4)()
+        _chk(load().yakhip_selftest_division(self._h, out))
+        return [int(v) for v in out]
 
     def synchronize(self):
         _chk(load().yakhip_ctx_synchronize(self._h))

@@ -103,6 +103,8 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->group_test = 1;
   ctx->thr = nullptr;
   ctx->thr_bytes = 0;
+  ctx->kernel_timing = 0;
+  ctx->timing_used = 0;
   int rc = check(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
   if (rc != 0)
   {
@@ -124,6 +126,11 @@ int yakhip_ctx_destroy(yakhip_ctx* ctx)
     rc = check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     if (ctx->thr)
       (void)hipFree(ctx->thr);
+    for (auto& ev : ctx->timing_events)
+    {
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
     int rc2 = check(hipStreamDestroy(ctx->own_stream), "hipStreamDestroy");
     if (rc == 0)
       rc = rc2;
@@ -179,6 +186,12 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
     ctx->force_vx = value;
     return 0;
   }
+  if (strcmp(key, "kernel_timing") == 0)
+  {
+    ctx->kernel_timing = value != 0;
+    ctx->timing_used = 0;  // restart the accumulation
+    return 0;
+  }
   if (strcmp(key, "group_test") == 0)
   {
     ctx->group_test = value != 0;
@@ -192,6 +205,37 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
     return 0;
   }
   return fail(YAKHIP_EINVAL, "unknown option '%s'", key);
+}
+
+int yakhip_ctx_kernel_time(yakhip_ctx* ctx, double* total_ms, int* launches)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!total_ms || !launches)
+    return fail(YAKHIP_EINVAL, "kernel_time: null out pointer");
+  double sum = 0.0;
+  for (size_t i = 0; i < ctx->timing_used; ++i)
+  {
+    YAKHIP_TRY(hipEventSynchronize(ctx->timing_events[i].second));
+    float ms = 0.f;
+    YAKHIP_TRY(hipEventElapsedTime(&ms, ctx->timing_events[i].first, ctx->timing_events[i].second));
+    sum += ms;
+  }
+  *total_ms = sum;
+  *launches = (int)ctx->timing_used;
+  ctx->timing_used = 0;
+  return 0;
+}
+
+int yakhip_selftest_division(yakhip_ctx* ctx, unsigned long long counts[4])
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!counts)
+    return fail(YAKHIP_EINVAL, "selftest: null out pointer");
+  return launch_selftest_division(ctx, counts);
 }
 
 // ---- device memory ------------------------------------------------------------------------------

@@ -79,7 +79,7 @@ __device__ __forceinline__ void vset<1>(uint32_t& v, int, uint32_t x)
 
 // ---- correctly rounded fp32 division in 3 + 3 instructions -------------------------------------
 // refined_rcp(d) = v_rcp_f32 + one Newton step.  On gfx950 it equals the correctly rounded 1/d for
-// EVERY fp32 mantissa (checked exhaustively on the device: tests/test_division_gpu.py; the
+// EVERY fp32 mantissa (checked exhaustively on the device by yakhip_selftest_division, tests/test_division_gpu.py; the
 // arithmetic is exponent-invariant while nothing under/overflows).  With y = RN(1/d) and
 // q0 = RN(n*y), Markstein's theorem gives RN(q0 + (n - d*q0)*y) = RN(n/d): the correctly rounded
 // quotient, i.e. bit-identical to IEEE '/'.  Callers keep d inside [2^-20, 2^20]; numerators so
@@ -587,13 +587,28 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
 }
 
 template <int VX>
-static int launch_variant(const yakhip_ctx* ctx, const IntegrateParams& p, dim3 grid)
+static int launch_variant(yakhip_ctx* ctx, const IntegrateParams& p, dim3 grid)
 {
   const size_t lds = VX == 4 && p.grp_enable ? (size_t)p.cw * p.ch * sizeof(float) : 0;
+  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  if (ctx->kernel_timing)  // measurement aid: one event pair around this kernel only
+  {
+    if (ctx->timing_used == ctx->timing_events.size())
+    {
+      std::pair<hipEvent_t, hipEvent_t> e;
+      YAKHIP_TRY(hipEventCreate(&e.first));
+      YAKHIP_TRY(hipEventCreate(&e.second));
+      ctx->timing_events.push_back(e);
+    }
+    ev = &ctx->timing_events[ctx->timing_used++];
+    YAKHIP_TRY(hipEventRecord(ev->first, ctx->stream));
+  }
   if (ctx->nontemporal)
     hipLaunchKernelGGL((integrate_kernel<VX, true>), grid, dim3(256), lds, ctx->stream, p);
   else
     hipLaunchKernelGGL((integrate_kernel<VX, false>), grid, dim3(256), lds, ctx->stream, p);
+  if (ev)
+    YAKHIP_TRY(hipEventRecord(ev->second, ctx->stream));
   return check(hipGetLastError(), "integrate_kernel launch");
 }
 
@@ -676,12 +691,13 @@ int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in)
   const uint32_t blocks_x = (groups + 255u) / 256u;
   const int layers = p.z1 - p.z0;
 
-  // z_chunk: enough workgroups to keep >= 4 waves on every SIMD, but long enough that the replay
-  // of layers [0, zs) stays a small fraction of the chunk's own work.
+  // z_chunk: the kernel is software-pipelined, so two or three 4-wave workgroups per CU already
+  // saturate HBM; longer chunks mean less replay of layers [0, zs) and fewer prologues, shorter ones
+  // balance scenes whose cost varies across the volume.  Aim for ~3 workgroups per CU.
   int chunk = ctx->z_chunk;
   if (chunk <= 0)
   {
-    const uint32_t want_blocks = 1024u;
+    const uint32_t want_blocks = 768u;
     uint32_t nchunks = (want_blocks + blocks_x - 1u) / blocks_x;
     if (nchunks < 1u)
       nchunks = 1u;
@@ -713,6 +729,65 @@ int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in)
     default:
       return launch_variant<1>(ctx, p, grid);
   }
+}
+
+// ---- self-test of the division building blocks (yakhip_selftest_division) -----------------------
+__global__ __launch_bounds__(256) void selftest_rcp_kernel(unsigned long long* bad)
+{
+  // every fp32 mantissa at several exponents: refined_rcp(d) must be the correctly rounded 1/d
+  const uint32_t m = blockIdx.x * 256u + threadIdx.x;  // 0 .. 2^23-1
+  const uint32_t exps[8] = { 107u, 113u, 120u, 126u, 127u, 128u, 137u, 147u };  // 2^-20 .. 2^20
+  unsigned long long n = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+  {
+    const float d = __uint_as_float((exps[k] << 23) | m);
+    n += __float_as_uint(refined_rcp(d)) != __float_as_uint(1.0f / d);
+  }
+  if (n)
+    atomicAdd(bad, n);
+}
+
+__global__ __launch_bounds__(256) void selftest_div_kernel(unsigned long long* bad, int iters, uint64_t seed)
+{
+  // pseudo-random numerators in +-[2^-30, 2^16] over denominators in [2^-20, 2^20] and over the
+  // integers 1..32768 (the running-average divisor): div_by must equal IEEE '/'
+  uint64_t s = seed + (uint64_t)(blockIdx.x * 256u + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+  unsigned long long n = 0;
+  for (int i = 0; i < iters; ++i)
+  {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    const uint32_t a = (uint32_t)(s >> 32);
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    const uint32_t b = (uint32_t)(s >> 32);
+    const float num = __uint_as_float((a & 0x807fffffu) | ((97u + (a >> 23) % 47u) << 23));
+    const float d1 = __uint_as_float((b & 0x007fffffu) | ((107u + (b >> 23) % 41u) << 23));
+    const float d2 = (float)(1u + (b % 32768u));
+    n += __float_as_uint(div_by(num, d1, refined_rcp(d1))) != __float_as_uint(num / d1);
+    n += __float_as_uint(div_by(num, d2, refined_rcp(d2))) != __float_as_uint(num / d2);
+  }
+  if (n)
+    atomicAdd(bad, n);
+}
+
+int launch_selftest_division(yakhip_ctx* ctx, unsigned long long counts[4])
+{
+  unsigned long long* dev = nullptr;
+  YAKHIP_TRY(hipMalloc(&dev, 2 * sizeof(unsigned long long)));
+  YAKHIP_TRY(hipMemsetAsync(dev, 0, 2 * sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(selftest_rcp_kernel, dim3((1u << 23) / 256u), dim3(256), 0, ctx->stream, dev);
+  const int blocks = 2048, iters = 1024;
+  hipLaunchKernelGGL(selftest_div_kernel, dim3(blocks), dim3(256), 0, ctx->stream, dev + 1, iters, 0x5eedull);
+  unsigned long long host[2] = { ~0ull, ~0ull };
+  int rc = check(hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+  if (rc == 0)
+    rc = check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+  (void)hipFree(dev);
+  counts[0] = 8ull << 23;                                  // reciprocals checked
+  counts[1] = host[0];                                     // ... that differ from 1.0f / d
+  counts[2] = 2ull * (unsigned long long)blocks * 256ull * (unsigned long long)iters;  // quotients checked
+  counts[3] = host[1];                                     // ... that differ from n / d
+  return rc;
 }
 
 // ---- clear: tsdf_volume.cu:14-40.  pack_tsdf(0.f, 0) is the all-zero word. ----------------------

@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+#include <vector>
+
 #include "yakhip.h"
 
 struct yakhip_ctx
@@ -18,6 +21,9 @@ struct yakhip_ctx
   int group_test;      // coarse group test on (default) / off
   void* thr;           // scratch: per-pixel band thresholds of the frame being integrated
   size_t thr_bytes;
+  int kernel_timing;   // record a hipEvent pair around every integrate_kernel launch
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_events;
+  size_t timing_used;
 };
 
 namespace yakhip
@@ -65,6 +71,7 @@ struct IntegrateParams
 
 int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p);
 int launch_clear(const yakhip_ctx* ctx, uint32_t* data, size_t n_voxels);
+int launch_selftest_division(yakhip_ctx* ctx, unsigned long long counts[4]);
 int launch_compute_dists(const yakhip_ctx* ctx, const uint8_t* depth, size_t depth_pitch, uint8_t* dists,
                          size_t dists_pitch, int rows, int cols, float fx, float fy, float cx, float cy);
 
