@@ -1,0 +1,274 @@
+// Host-layer tests, in the style the reference tests its own host code (gtest-like cases, no gtest
+// in this image): `test_host --cpu` needs no GPU; `test_host --gpu` drives yak::FusionServer on a
+// real device and checks the downloaded volume word for word against the CPU oracle.
+#include <yak/yak_server.h>
+
+#include <yak_oracle.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+static int g_failed = 0;
+#define EXPECT(cond)                                                         \
+  do                                                                         \
+  {                                                                          \
+    if (!(cond))                                                             \
+    {                                                                        \
+      std::printf("  FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond);          \
+      ++g_failed;                                                            \
+    }                                                                        \
+  } while (0)
+
+using kfusion::Affine3f;
+using kfusion::Vec3f;
+
+static Affine3f rot_y_translate(float angle, float tx, float ty, float tz)
+{
+  kfusion::Mat3f R = kfusion::Mat3f::eye();
+  R(0, 0) = std::cos(angle);
+  R(0, 2) = std::sin(angle);
+  R(2, 0) = -std::sin(angle);
+  R(2, 2) = std::cos(angle);
+  return Affine3f(R, Vec3f(tx, ty, tz));
+}
+
+// ---------------------------------------------------------------------------------------- CPU
+static void test_params_defaults()  // reference kinfu.cpp:10-48
+{
+  std::printf("KinFuParams.default_params\n");
+  const kfusion::KinFuParams p = kfusion::KinFuParams::default_params();
+  EXPECT(p.cols == 640 && p.rows == 480);
+  EXPECT(p.intr.fx == 580.f && p.intr.fy == 580.f && p.intr.cx == 319.5f && p.intr.cy == 239.5f);
+  EXPECT(p.volume_dims[0] == 512 && p.volume_dims[1] == 512 && p.volume_dims[2] == 512);
+  EXPECT(p.volume_resolution == 0.005859375f);
+  EXPECT(p.tsdf_trunc_dist == 0.04f && p.tsdf_max_weight == 64 && p.tsdf_min_camera_movement == 0.f);
+  EXPECT(p.icp_iter_num.size() == 4 && p.icp_iter_num[0] == 10 && p.icp_iter_num[3] == 0);
+  EXPECT(p.raycast_step_factor == 0.75f && p.gradient_delta_factor == 0.5f);
+  EXPECT(p.use_icp && !p.use_pose_hints && p.update_via_sensor_motion);
+  const kfusion::Intr l2 = p.intr(2);  // precomp.cpp:10-14
+  EXPECT(l2.fx == 145.f && l2.cx == 319.5f / 4);
+}
+
+static void test_affine_math()
+{
+  std::printf("compat.Affine3f\n");
+  const Affine3f a = rot_y_translate(0.3f, 0.5f, -1.25f, 2.f), b = rot_y_translate(-1.1f, 3.f, 0.25f, -0.5f);
+  const Affine3f id = a * a.inv();
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c)
+      EXPECT(std::fabs(id.matrix(r, c) - (r == c ? 1.f : 0.f)) < 1e-6f);
+  const Vec3f v(0.2f, 0.4f, -0.7f);
+  const Vec3f l = (a * b) * v, r2 = a * (b * v);
+  EXPECT(std::fabs(l[0] - r2[0]) < 1e-5f && std::fabs(l[1] - r2[1]) < 1e-5f && std::fabs(l[2] - r2[2]) < 1e-5f);
+  const Vec3f rv = a.rvec();  // rotation about +y by 0.3 rad
+  EXPECT(std::fabs(rv[0]) < 1e-6f && std::fabs(rv[1] - 0.3f) < 1e-6f && std::fabs(rv[2]) < 1e-6f);
+  const Affine3f back(rv, a.translation());  // Rodrigues round trip
+  for (int i = 0; i < 9; ++i)
+    EXPECT(std::fabs(back.rotation().val[i] - a.rotation().val[i]) < 1e-6f);
+}
+
+static void test_container_and_half()  // reference test/marching_cubes_tests.cpp:63-79, tsdf_container.h:21-49
+{
+  std::printf("TSDFContainer / Entry\n");
+  yak::TSDFContainer c(3, 4, 5);
+  EXPECT(c.size() == 60 && c.toIndex(1, 2, 3) == 3 * 4 * 3 + 3 * 2 + 1 && c.toIndex64(1, 2, 3) == 43u);
+  int x, y, z;
+  c.fromIndex(43, x, y, z);
+  EXPECT(x == 1 && y == 2 && z == 3);
+  c.data()[43] = 0x00133600u;  // half(0.375), weight 19
+  std::uint16_t d, w;
+  c.read(43, d, w);
+  EXPECT(d == 0x3600 && w == 19 && c.distance(43) == 0.375f);
+  typedef kfusion::cuda::TsdfVolume::Entry E;
+  EXPECT(E::float2half(0.375f) == 0x3600 && E::half2float(0x3600) == 0.375f);
+  for (unsigned h = 0; h < 65536; ++h)  // against the oracle's conversions
+  {
+    const float f = E::half2float((E::half)h);
+    if (f == f)
+    {
+      const float o = yko_half2float((uint16_t)h);
+      EXPECT(std::memcmp(&f, &o, 4) == 0);
+      EXPECT(E::float2half(f) == h);
+    }
+  }
+  kfusion::cuda::ProjectiveICP icp;  // levels with a non-zero iteration count: {10,5,4,0} -> 3
+  EXPECT(icp.getUsedLevelsNum() == 3);
+}
+
+static void test_no_gpu_is_an_exception()
+{
+  std::printf("no GPU -> std::runtime_error (never exit)\n");
+  if (kfusion::cuda::getCudaEnabledDeviceCount() > 0)
+  {
+    std::printf("  (a GPU is present, skipped)\n");
+    return;
+  }
+  bool threw = false;
+  try
+  {
+    kfusion::KinFuParams p = kfusion::KinFuParams::default_params();
+    p.volume_dims = kfusion::Vec3i::all(8);
+    kfusion::KinFu k(p);
+  }
+  catch (const std::runtime_error&)
+  {
+    threw = true;
+  }
+  EXPECT(threw);
+}
+
+// ---------------------------------------------------------------------------------------- GPU
+// analytic depth frame: wall z_world = 3.4 and a sphere, seen from camera pose `cam` (camera -> volume)
+static std::vector<std::uint16_t> render(const Affine3f& cam, const kfusion::Intr& in, int rows, int cols)
+{
+  std::vector<std::uint16_t> depth((size_t)rows * cols, 0);
+  const kfusion::Mat3f R = cam.rotation();
+  const Vec3f o = cam.translation();
+  const double cx = 1.5, cy = 1.5, cz = 1.6, rad = 0.8;
+  for (int v = 0; v < rows; ++v)
+    for (int u = 0; u < cols; ++u)
+    {
+      const double dc[3] = { (u - in.cx) / in.fx, (v - in.cy) / in.fy, 1.0 };
+      double d[3];
+      for (int i = 0; i < 3; ++i)
+        d[i] = R(i, 0) * dc[0] + R(i, 1) * dc[1] + R(i, 2) * dc[2];
+      double best = 1e30;
+      if (std::fabs(d[2]) > 1e-12)
+      {
+        const double s = (3.4 - o[2]) / d[2];
+        if (s > 1e-6)
+          best = s;
+      }
+      const double oc[3] = { o[0] - cx, o[1] - cy, o[2] - cz };
+      const double a = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], b = 2 * (d[0] * oc[0] + d[1] * oc[1] + d[2] * oc[2]),
+                   c = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2] - rad * rad, disc = b * b - 4 * a * c;
+      if (disc >= 0)
+      {
+        const double s = (-b - std::sqrt(disc)) / (2 * a);
+        if (s > 1e-6 && s < best)
+          best = s;
+      }
+      const double mm = std::floor(best * 1000.0 + 0.5);
+      depth[(size_t)v * cols + u] = (best < 1e29 && mm > 0 && mm < 65535) ? (std::uint16_t)mm : 0;
+    }
+  return depth;
+}
+
+static void oracle_frame(std::vector<std::uint32_t>& vol, const kfusion::cuda::TsdfVolume& tv, const Affine3f& cam_pose,
+                         const std::vector<std::uint16_t>& depth, const kfusion::KinFuParams& p)
+{
+  std::vector<std::uint16_t> dists(depth.size());
+  yko_compute_dists(depth.data(), p.cols * 2, dists.data(), p.cols * 2, p.rows, p.cols, p.intr.fx, p.intr.fy, p.intr.cx,
+                    p.intr.cy);
+  const Affine3f vol2cam = cam_pose.inv() * tv.getPose();  // tsdf_volume.cpp:97, same host arithmetic
+  const kfusion::Vec3i dims = tv.getDims();
+  const Vec3f vs = tv.getVoxelSize();
+  const int d[3] = { dims[0], dims[1], dims[2] };
+  const float vsz[3] = { vs[0], vs[1], vs[2] }, t[3] = { vol2cam.translation()[0], vol2cam.translation()[1],
+                                                          vol2cam.translation()[2] };
+  const float intr[4] = { p.intr.fx, p.intr.fy, p.intr.cx, p.intr.cy };
+  yko_integrate(vol.data(), d, 0, d[2], vsz, tv.getTruncDist(), tv.getMaxWeight(), dists.data(), p.cols * 2, p.rows,
+                p.cols, vol2cam.rotation().val, t, intr, nullptr, 8);
+}
+
+static void test_fusion_server_against_oracle()
+{
+  std::printf("FusionServer.fuse / downloadTSDF vs oracle\n");
+  kfusion::KinFuParams p = kfusion::KinFuParams::default_params();
+  p.volume_dims = kfusion::Vec3i(64, 48, 56);
+  p.volume_resolution = 3.f / 64.f;
+  p.use_icp = false;
+  p.use_pose_hints = true;
+  p.update_via_sensor_motion = false;
+  yak::FusionServer server(p, Eigen::Affine3f::Identity());
+
+  std::vector<std::uint32_t> want((size_t)64 * 48 * 56, 0u);
+  kfusion::KinFu probe(p);  // only to read the volume parameters the host derives
+  // trunc clamp (tsdf_volume.cpp:62-67) is sticky through the constructor order (kinfu.cpp:52-61): the
+  // volume is born 3 m wide, so with 48 voxels in y the first clamp is 2.1 * 3/48, and the later
+  // setSize() re-clamps that value, not the requested 0.04
+  EXPECT(std::fabs(probe.tsdf().getTruncDist() - 2.1f * (3.f / 48.f)) < 1e-7f);
+  EXPECT(probe.tsdf().getMaxWeight() == 64);
+
+  const Affine3f poses[4] = { rot_y_translate(0.f, 1.5f, 1.2f, -2.0f), rot_y_translate(0.1f, 1.1f, 1.25f, -2.1f),
+                              rot_y_translate(-0.15f, 1.9f, 1.1f, -1.9f), rot_y_translate(0.25f, 0.8f, 1.3f, -2.2f) };
+  for (int f = 0; f < 4; ++f)
+  {
+    std::vector<std::uint16_t> depth = render(poses[f], p.intr, p.rows, p.cols);
+    const cv::Mat m(p.rows, p.cols, depth.data(), (size_t)p.cols * 2);
+    const bool ok = server.fuse(m, Eigen::Affine3f(poses[f]));
+    EXPECT(ok == (f > 0));  // frame 0 integrates but reports false (kinfu.cpp:200)
+    // frame 0 integrates at params.volume_pose, not at the pose passed in (kinfu.cpp:193)
+    oracle_frame(want, probe.tsdf(), f == 0 ? p.volume_pose : poses[f], depth, p);
+    const yak::TSDFContainer got = server.downloadTSDF();
+    EXPECT(got.size64() == want.size());
+    size_t diff = 0, touched = 0;
+    for (size_t i = 0; i < want.size(); ++i)
+    {
+      diff += got.data()[i] != want[i];
+      touched += want[i] != 0;
+    }
+    std::printf("  frame %d: %zu voxels set, %zu differ\n", f, touched, diff);
+    EXPECT(diff == 0);
+    EXPECT(f == 0 || touched > 1000);
+  }
+  EXPECT(server.reset());
+  const yak::TSDFContainer cleared = server.downloadTSDF();
+  size_t nz = 0;
+  for (size_t i = 0; i < cleared.size64(); ++i)
+    nz += cleared.data()[i] != 0;
+  EXPECT(nz == 0);
+}
+
+static void test_device_arrays()
+{
+  std::printf("DeviceArray / DeviceArray2D\n");
+  std::vector<unsigned short> host(37 * 53);
+  for (size_t i = 0; i < host.size(); ++i)
+    host[i] = (unsigned short)(i * 7u);
+  kfusion::cuda::Depth d;
+  d.upload(host.data(), 53 * 2, 37, 53);
+  EXPECT(d.rows() == 37 && d.cols() == 53 && d.step() >= 106 && d.step() % 256 == 0);
+  kfusion::cuda::Depth alias = d, copy;
+  d.copyTo(copy);
+  std::vector<unsigned short> back(host.size(), 0);
+  copy.download(back.data(), 53 * 2);
+  EXPECT(back == host);
+  EXPECT(alias.ptr() == d.ptr() && copy.ptr() != d.ptr());
+  d.release();
+  EXPECT(d.empty() && !alias.empty());
+  kfusion::cuda::DeviceArray<int> a(100);
+  EXPECT(a.size() == 100 && a.sizeBytes() == 400);
+}
+
+int main(int argc, char** argv)
+{
+  const std::string mode = argc > 1 ? argv[1] : "--cpu";
+  try
+  {
+    if (mode == "--cpu")
+    {
+      test_params_defaults();
+      test_affine_math();
+      test_container_and_half();
+      test_no_gpu_is_an_exception();
+    }
+    else
+    {
+      std::printf("device: %s\n", kfusion::cuda::getDeviceName(0).c_str());
+      test_device_arrays();
+      test_fusion_server_against_oracle();
+    }
+  }
+  catch (const std::exception& e)
+  {
+    std::printf("  FAIL uncaught exception: %s\n", e.what());
+    ++g_failed;
+  }
+  std::printf(g_failed ? "FAILED (%d)\n" : "PASSED\n", g_failed);
+  return g_failed ? 1 : 0;
+}

@@ -1,0 +1,38 @@
+"""The C++ host layer (include/yak/..., yak_amd/host/): the reference's class names over the C ABI.
+The cases live in tests/cpp/test_host.cpp (built by __graft_entry__.build()); this file runs them."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "test_host")
+
+
+def run(mode):
+    assert os.path.exists(EXE), "tests/cpp/test_host missing: run __graft_entry__.build()"
+    r = subprocess.run([EXE, mode], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    print(r.stderr)
+    assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout[-2000:]
+
+
+def test_host_layer_cpu_cases():
+    run("--cpu")
+
+
+def test_frontend_library_exports_reference_class_names():
+    lib = os.path.join(ROOT, "yak_amd", "host", "libyak_frontend.so")
+    assert os.path.exists(lib)
+    syms = subprocess.run(["nm", "-DC", "--defined-only", lib], capture_output=True, text=True).stdout
+    for name in ["yak::FusionServer::fuse(", "yak::FusionServer::downloadTSDF()", "kfusion::KinFu::operator()(",
+                 "kfusion::KinFuParams::default_params()", "kfusion::cuda::TsdfVolume::integrate(",
+                 "kfusion::cuda::TsdfVolume::clear()", "kfusion::cuda::computeDists(",
+                 "kfusion::cuda::DeviceMemory2D::upload(", "kfusion::cuda::getCudaEnabledDeviceCount()",
+                 "yak::TSDFContainer::TSDFContainer(int, int, int)"]:
+        assert name in syms, name
+
+
+@pytest.mark.gpu
+def test_host_layer_gpu_fusion_server_matches_oracle():
+    run("--gpu")

@@ -1,0 +1,222 @@
+// kfusion::cuda::TsdfVolume host side (reference yak/src/kfusion/tsdf_volume.cpp:19-145) and the
+// imgproc wrappers this path needs (reference yak/src/kfusion/imgproc.cpp:21,45-49).
+#include <yak/kfusion/cuda/imgproc.hpp>
+#include <yak/kfusion/cuda/tsdf_volume.hpp>
+
+#include <yakhip.h>
+
+#include <algorithm>
+#include <ostream>
+#include <stdexcept>
+
+#define YAK_CHECK(call)                                                       \
+  do                                                                          \
+  {                                                                           \
+    if ((call) != 0)                                                          \
+      ::kfusion::cuda::error(yakhip_last_error(), __FILE__, __LINE__, #call); \
+  } while (0)
+
+namespace kfusion
+{
+// reference precomp.cpp:7-19
+Intr::Intr() : fx(0), fy(0), cx(0), cy(0) {}
+Intr::Intr(float fx_, float fy_, float cx_, float cy_) : fx(fx_), fy(fy_), cx(cx_), cy(cy_) {}
+Intr Intr::operator()(int level_index) const
+{
+  const int div = 1 << level_index;
+  return Intr(fx / div, fy / div, cx / div, cy / div);
+}
+std::ostream& operator<<(std::ostream& os, const Intr& intr)
+{
+  return os << "([f = " << intr.fx << ", " << intr.fy << "] [cp = " << intr.cx << ", " << intr.cy << "])";
+}
+
+namespace cuda
+{
+// reference tsdf_volume.cpp:9-14 throws "Not implemented" from both; they are implemented here
+float TsdfVolume::Entry::half2float(half value)
+{
+  const unsigned sign = (value & 0x8000u) << 16, exp = (value >> 10) & 0x1fu;
+  unsigned mant = value & 0x3ffu, bits;
+  if (exp == 0)
+  {
+    if (mant == 0)
+      bits = sign;
+    else
+    {
+      int e = -1;
+      do
+      {
+        ++e;
+        mant <<= 1;
+      } while (!(mant & 0x400u));
+      bits = sign | ((unsigned)(112 - e) << 23) | ((mant & 0x3ffu) << 13);
+    }
+  }
+  else if (exp == 31)
+    bits = sign | 0x7f800000u | (mant << 13);
+  else
+    bits = sign | ((exp + 112u) << 23) | (mant << 13);
+  float f;
+  std::memcpy(&f, &bits, 4);
+  return f;
+}
+TsdfVolume::Entry::half TsdfVolume::Entry::float2half(float value)
+{
+  unsigned u;
+  std::memcpy(&u, &value, 4);
+  const unsigned sign = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+  if (a >= 0x7f800000u)
+    return (half)(sign | 0x7c00u | (a > 0x7f800000u ? 0x200u : 0u));
+  if (a >= 0x477ff000u)
+    return (half)(sign | 0x7c00u);
+  if (a < 0x33000001u)
+    return (half)sign;
+  const int exp = (int)(a >> 23);
+  unsigned mant = a & 0x7fffffu, h;
+  if (exp >= 113)
+  {
+    h = ((unsigned)(exp - 112) << 10) | (mant >> 13);
+    const unsigned rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u)))
+      ++h;
+  }
+  else
+  {
+    mant |= 0x800000u;
+    const int shift = 126 - exp;
+    h = mant >> shift;
+    const unsigned rem = mant & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (h & 1u)))
+      ++h;
+  }
+  return (half)(sign | h);
+}
+
+// reference tsdf_volume.cpp:19-30: defaults trunc 0.03, max weight 128, 3 m cube, identity pose
+TsdfVolume::TsdfVolume(const Vec3i& dims)
+  : data_()
+  , trunc_dist_(0.03f)
+  , max_weight_(128)
+  , dims_(dims)
+  , size_(Vec3f::all(3.f))
+  , pose_(Affine3f::Identity())
+  , gradient_delta_factor_(0.75f)
+  , raycast_step_factor_(0.75f)
+{
+  create(dims_);
+}
+TsdfVolume::~TsdfVolume() {}
+
+// :34-41 (the reference sizes the buffer with an int product; size_t here)
+void TsdfVolume::create(const Vec3i& dims)
+{
+  dims_ = dims;
+  const size_t voxels = (size_t)dims_[0] * (size_t)dims_[1] * (size_t)dims_[2];
+  data_.create(voxels * sizeof(int));
+  setTruncDist(trunc_dist_);
+  clear();
+}
+Vec3i TsdfVolume::getDims() const { return dims_; }
+Vec3f TsdfVolume::getVoxelSize() const  // :45-48
+{
+  return Vec3f(size_[0] / dims_[0], size_[1] / dims_[1], size_[2] / dims_[2]);
+}
+const CudaData TsdfVolume::data() const { return data_; }
+CudaData TsdfVolume::data() { return data_; }
+Vec3f TsdfVolume::getSize() const { return size_; }
+void TsdfVolume::setSize(const Vec3f& size)  // :54-58
+{
+  size_ = size;
+  setTruncDist(trunc_dist_);
+}
+float TsdfVolume::getTruncDist() const { return trunc_dist_; }
+void TsdfVolume::setTruncDist(float distance)  // :62-67
+{
+  const Vec3f vsz = getVoxelSize();
+  const float max_coeff = std::max<float>(std::max<float>(vsz[0], vsz[1]), vsz[2]);
+  trunc_dist_ = std::max(distance, 2.1f * max_coeff);
+}
+int TsdfVolume::getMaxWeight() const { return max_weight_; }
+void TsdfVolume::setMaxWeight(int weight)
+{
+  // the weight lane is a signed 16-bit value on the reference's device path (device.hpp:69-77)
+  max_weight_ = std::max(1, std::min(weight, 32767));
+}
+Affine3f TsdfVolume::getPose() const { return pose_; }
+void TsdfVolume::setPose(const Affine3f& pose) { pose_ = pose; }
+float TsdfVolume::getRaycastStepFactor() const { return raycast_step_factor_; }
+void TsdfVolume::setRaycastStepFactor(float factor) { raycast_step_factor_ = factor; }
+float TsdfVolume::getGradientDeltaFactor() const { return gradient_delta_factor_; }
+void TsdfVolume::setGradientDeltaFactor(float factor) { gradient_delta_factor_ = factor; }
+void TsdfVolume::swap(CudaData& data) { data_.swap(data); }
+void TsdfVolume::applyAffine(const Affine3f& affine) { pose_ = affine * pose_; }
+
+namespace
+{
+yakhip_volume make_view(void* data, const Vec3i& dims, const Vec3f& vsz, float trunc, int max_weight)
+{
+  yakhip_volume v;
+  v.data = data;
+  for (int i = 0; i < 3; ++i)
+  {
+    v.dims[i] = dims[i];
+    v.voxel_size[i] = vsz[i];
+  }
+  v.z0 = 0;
+  v.z1 = dims[2];
+  v.trunc_dist = trunc;
+  v.max_weight = max_weight;
+  return v;
+}
+}  // namespace
+
+void TsdfVolume::clear()  // :80-87
+{
+  yakhip_volume v = make_view(data_.ptr<void>(), dims_, getVoxelSize(), trunc_dist_, max_weight_);
+  YAK_CHECK(yakhip_clear_volume(context(), &v));
+}
+
+// :89-108.  vol2cam = camera_pose^-1 * pose_; the device layer takes it as row-major R and t
+// (precomp.hpp:15-30).  Blocking, like the reference (tsdf_volume.cu:139).
+void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_motion_tform, const Intr& intr)
+{
+  const Affine3f vol2cam = camera_motion_tform.inv() * pose_;
+  const Mat3f R = vol2cam.rotation();
+  const Vec3f t = vol2cam.translation();
+  const float Rf[9] = { R.val[0], R.val[1], R.val[2], R.val[3], R.val[4], R.val[5], R.val[6], R.val[7], R.val[8] };
+  const float tf[3] = { t[0], t[1], t[2] };
+  const float in[4] = { intr.fx, intr.fy, intr.cx, intr.cy };
+  yakhip_volume v = make_view(data_.ptr<void>(), dims_, getVoxelSize(), trunc_dist_, max_weight_);
+  YAK_CHECK(yakhip_integrate(context(), &v, dists.ptr(), dists.step(), dists.rows(), dists.cols(), Rf, tf, in));
+  YAK_CHECK(yakhip_ctx_synchronize(context()));
+}
+
+void TsdfVolume::raycast(const Affine3f&, const Intr&, Depth&, Normals&)
+{
+  throw std::logic_error("TsdfVolume::raycast(depth): not built yet (SURVEY section 8f rank 1)");
+}
+void TsdfVolume::raycast(const Affine3f&, const Intr&, Cloud&, Normals&)
+{
+  throw std::logic_error("TsdfVolume::raycast(points): not built yet (SURVEY section 8f rank 1)");
+}
+DeviceArray<Point> TsdfVolume::fetchCloud(DeviceArray<Point>&) const
+{
+  throw std::logic_error("TsdfVolume::fetchCloud: out of scope (unused by FusionServer, SURVEY section 2 #4)");
+}
+void TsdfVolume::fetchNormals(const DeviceArray<Point>&, DeviceArray<Normal>&) const
+{
+  throw std::logic_error("TsdfVolume::fetchNormals: out of scope (unused by FusionServer, SURVEY section 2 #4)");
+}
+
+// ---- imgproc wrappers ----
+void computeDists(const Depth& depth, Dists& dists, const Intr& intr)  // imgproc.cpp:45-49
+{
+  dists.create(depth.rows(), depth.cols());
+  const float in[4] = { intr.fx, intr.fy, intr.cx, intr.cy };
+  YAK_CHECK(yakhip_compute_dists(context(), depth.ptr(), depth.step(), dists.ptr(), dists.step(), depth.rows(),
+                                 depth.cols(), in));
+}
+void waitAllDefaultStream() { YAK_CHECK(yakhip_ctx_synchronize(context())); }  // imgproc.cpp:21
+}  // namespace cuda
+}  // namespace kfusion

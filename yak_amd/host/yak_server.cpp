@@ -1,0 +1,87 @@
+// yak::FusionServer and yak::TSDFContainer (reference yak/src/yak_server.cpp:4-110,
+// yak/src/kfusion/tsdf_container.cpp).
+#include <yak/yak_server.h>
+
+namespace yak
+{
+TSDFContainer::TSDFContainer(int x, int y, int z)
+  : data_(std::make_shared<std::vector<std::uint32_t>>((std::size_t)x * (std::size_t)y * (std::size_t)z, 0u))
+{
+  dims_.v[0] = x;
+  dims_.v[1] = y;
+  dims_.v[2] = z;
+}
+float TSDFContainer::distance(std::size_t index) const
+{
+  std::uint16_t d, w;
+  read(index, d, w);
+  return kfusion::cuda::TsdfVolume::Entry::half2float(d);
+}
+
+namespace
+{
+kfusion::Affine3f to_kf(const Eigen::Affine3f& e)
+{
+  kfusion::Affine3f a;
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c)
+      a.matrix(r, c) = e(r, c);
+  return a;
+}
+}  // namespace
+
+// yak_server.cpp:4-13 (no window)
+FusionServer::FusionServer(const kfusion::KinFuParams& params, const Eigen::Affine3f& world_to_volume)
+  : kinfu_(new kfusion::KinFu(params))
+  , volume_to_world_(world_to_volume.inverse())
+  , last_camera_pose_(Eigen::Affine3f::Identity())
+{
+}
+
+// yak_server.cpp:15-39
+bool FusionServer::fuse(const cv::Mat& depth_data, const Eigen::Affine3f& world_to_camera)
+{
+  const Eigen::Affine3f current_camera_in_volume = volume_to_world_ * world_to_camera;
+  Eigen::Affine3f motion = current_camera_in_volume * last_camera_pose_.inverse();
+  motion = motion.inverse();
+  depthDevice_.upload(depth_data.data, depth_data.step, depth_data.rows, depth_data.cols);
+  const bool result =
+      kinfu_->operator()(to_kf(motion), to_kf(current_camera_in_volume), to_kf(last_camera_pose_), depthDevice_);
+  last_camera_pose_ = current_camera_in_volume;
+  display();
+  return result;
+}
+
+bool FusionServer::reset()
+{
+  kinfu_->resetVolume();
+  return true;
+}
+bool FusionServer::resetWithNewParams(const kfusion::KinFuParams& params)
+{
+  kinfu_.reset(new kfusion::KinFu(params));
+  return true;
+}
+
+// yak_server.cpp:67-76
+yak::TSDFContainer FusionServer::downloadTSDF()
+{
+  const kfusion::cuda::TsdfVolume& vol = kinfu_->tsdf();
+  const kfusion::Vec3i dims = vol.getDims();
+  yak::TSDFContainer result(dims[0], dims[1], dims[2]);
+  vol.data().download(result.data());
+  return result;
+}
+
+// yak_server.cpp:78-88
+bool FusionServer::step(const Eigen::Affine3f& current_pose, const Eigen::Affine3f& last_pose, const cv::Mat& depth)
+{
+  Eigen::Affine3f s = current_pose * last_pose.inverse();
+  s = s.inverse();
+  depthDevice_.upload(depth.data, depth.step, depth.rows, depth.cols);
+  return kinfu_->operator()(to_kf(s), to_kf(current_pose), to_kf(last_pose), depthDevice_);
+}
+
+void FusionServer::display() {}
+void FusionServer::display(const Eigen::Affine3f&) {}
+}  // namespace yak
