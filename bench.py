@@ -30,8 +30,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 VOXELS_PER_RANK_EDGE = 512
 
-# global volume per world size: 512^3 voxels per rank, z kept as shallow as possible
-GLOBAL_DIMS = {1: (512, 512, 512), 2: (1024, 512, 512), 4: (1024, 1024, 512), 8: (1024, 1024, 1024)}
+from yak_amd.shard import BENCH_GLOBAL_DIMS as GLOBAL_DIMS, slab_range  # noqa: E402
 
 
 def wall_scene(dims, voxel):
@@ -131,9 +130,8 @@ def main():
     voxel = synth.VOLUME_SIZE_M / VOXELS_PER_RANK_EDGE
     _, _, tr = synth.volume_geometry(VOXELS_PER_RANK_EDGE)
     vs = (voxel, voxel, voxel)
-    layers = dims[2] // world
-    z0, z1 = rank * layers, (rank + 1) * layers
-    slab_voxels = dims[0] * dims[1] * layers
+    z0, z1 = slab_range(dims[2], world, rank)
+    slab_voxels = dims[0] * dims[1] * (z1 - z0)
 
     if args.scene == "s1" and world == 1:
         depth, R, t = synth.scene_s1()
