@@ -88,7 +88,7 @@ const char* yakhip_last_error(void);
 int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value);
 /* Measurement aid with no counterpart in the reference (its only timers are the never-invoked
  * ScopeTime/SampledScopeTime, yak/src/kfusion/core.cpp:236-260).  After
- * yakhip_ctx_set_option(ctx, "kernel_timing", 1) every integrate kernel launch is bracketed by a
+ * yakhip_ctx_set_option(ctx, "kernel_timing", 1) every integrate / raycast kernel launch is bracketed by a
  * hipEvent pair on the context's stream; this call waits for them, returns the summed device time of
  * those launches (milliseconds) and their count, and restarts the accumulation. */
 int yakhip_ctx_kernel_time(yakhip_ctx* ctx, double* total_ms, int* launches);
@@ -131,6 +131,30 @@ int yakhip_compute_dists(yakhip_ctx* ctx, const void* depth_dev, size_t depth_pi
  * position is accumulated from z = 0 exactly as tsdf_volume.cu:76 does). */
 int yakhip_integrate(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dists_dev, size_t dists_pitch, int rows,
                      int cols, const float R[9], const float t[3], const float intr[4]);
+
+/* ---- ray casting ------------------------------------------------------- */
+
+/* Replaces kfusion::device::raycast, Points overload (internal.hpp:137-144;
+ * yak/src/cuda/tsdf_volume.cu:288-352, 411-425): one ray per pixel through the whole volume
+ * (vol->z0 must be 0 and vol->z1 = dims[2]); first + -> - zero crossing of the nearest-voxel samples,
+ * refined by trilinear interpolation; vertex and normal are stored in the CAMERA frame.
+ * R,t = cam2vol and Rinv = its inverse rotation, as built at yak/src/kfusion/tsdf_volume.cpp:133-136.
+ * points / normals: rows x cols float4 {x, y, z, 0}, row pitch in bytes (multiple of 16); pixels
+ * without a hit hold quiet NaN in all four lanes (tsdf_volume.cu:298).
+ * step_factor, gradient_delta_factor: TsdfVolume::raycast_step_factor_ / gradient_delta_factor_
+ * (time step = trunc_dist * step_factor, gradient delta = voxel_size * gradient_delta_factor). */
+int yakhip_raycast_points(yakhip_ctx* ctx, const yakhip_volume* vol, const float R[9], const float t[3],
+                          const float Rinv[9], const float intr[4], float step_factor, float gradient_delta_factor,
+                          void* points_dev, size_t points_pitch, void* normals_dev, size_t normals_pitch, int rows,
+                          int cols);
+
+/* Replaces kfusion::device::raycast, Depth overload (internal.hpp:128-135;
+ * yak/src/cuda/tsdf_volume.cu:220-285, 395-409): as above, but stores depth(y,x) =
+ * (uint16)(vertex.z * 1000) millimetres, 0 where there is no hit. */
+int yakhip_raycast_depth(yakhip_ctx* ctx, const yakhip_volume* vol, const float R[9], const float t[3],
+                         const float Rinv[9], const float intr[4], float step_factor, float gradient_delta_factor,
+                         void* depth_dev, size_t depth_pitch, void* normals_dev, size_t normals_pitch, int rows,
+                         int cols);
 
 #ifdef __cplusplus
 }

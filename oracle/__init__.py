@@ -63,6 +63,10 @@ def lib():
         L.yko_integrate.restype = None
         L.yko_integrate.argtypes = [_u32p, _i32p, C.c_int, C.c_int, _f32p, C.c_float, C.c_int,
                                     _u16p, C.c_size_t, C.c_int, C.c_int, _f32p, _f32p, _f32p, _u64p, C.c_int]
+        L.yko_raycast.restype = None
+        L.yko_raycast.argtypes = [_u32p, _i32p, _f32p, C.c_float, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_float,
+                                  C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                  C.c_size_t, _u64p, C.c_int]
         L.yko_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -130,6 +134,26 @@ def integrate(slab, dims, voxel_size, trunc_dist, max_weight, dists, R, t, intr,
         np.ascontiguousarray(R, dtype=np.float32).reshape(-1), np.ascontiguousarray(t, dtype=np.float32),
         np.ascontiguousarray(intr, dtype=np.float32), stats, int(nthreads))
     return int(stats[0]), int(stats[1])
+
+
+def raycast(volume, dims, voxel_size, trunc_dist, R, t, Rinv, intr, rows, cols, step_factor=0.75,
+            gradient_delta_factor=0.5, want_depth=False, nthreads=1):
+    """Ray-cast the whole volume from cam2vol = (R, t).  Returns (points|depth, normals, fetches, hits):
+    points/normals are (rows, cols, 4) float32 (NaN where no hit), depth is (rows, cols) uint16 mm."""
+    dims = np.ascontiguousarray(dims, dtype=np.int32)
+    assert volume.dtype == np.uint32 and volume.flags.c_contiguous
+    assert volume.size == int(dims[0]) * int(dims[1]) * int(dims[2])
+    normals = np.empty((rows, cols, 4), dtype=np.float32)
+    points = None if want_depth else np.empty((rows, cols, 4), dtype=np.float32)
+    depth = np.empty((rows, cols), dtype=np.uint16) if want_depth else None
+    stats = np.zeros(2, dtype=np.uint64)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32).reshape(-1)  # noqa: E731
+    lib().yko_raycast(
+        volume.reshape(-1), dims, f32(voxel_size), float(trunc_dist), f32(R), f32(t), f32(Rinv), f32(intr),
+        float(step_factor), float(gradient_delta_factor), int(rows), int(cols),
+        points.ctypes.data if points is not None else None, cols * 16, normals.ctypes.data, cols * 16,
+        depth.ctypes.data if depth is not None else None, cols * 2, stats, int(nthreads))
+    return (depth if want_depth else points), normals, int(stats[0]), int(stats[1])
 
 
 def max_threads():

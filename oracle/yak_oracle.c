@@ -259,6 +259,218 @@ void yko_integrate(uint32_t* slab, const int dims[3], int z0, int z1, const floa
   }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Ray casting: tsdf_volume.cu:149-425.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct
+{
+  const uint32_t* vol;
+  int X, Y, Z;
+  float vsx, vsy, vsz;       /* voxel_size */
+  float ivx, ivy, ivz;       /* voxel_size_inv = 1.f / voxel_size  (cu:402) */
+  float gdx, gdy, gdz;       /* gradient_delta = voxel_size * factor  (cu:401) */
+  float szx, szy, szz;       /* volume_size = voxel_size * dims  (cu:399) */
+  float time_step;           /* trunc_dist * raycast_step_factor  (cu:400) */
+  const float *R, *t, *Rinv; /* aff = cam2vol, Rinv */
+  float finvx, finvy, cx, cy; /* Reprojector, precomp.cpp:73-76 */
+} Raycaster;
+
+static inline float voxel_tsdf(const Raycaster* rc, int x, int y, int z)
+{
+  return yko_half2float((uint16_t)(rc->vol[(size_t)x + (size_t)rc->X * ((size_t)y + (size_t)rc->Y * (size_t)z)] & 0xffffu));
+}
+
+static inline int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+/* cu:209-217  nearest voxel, round-half-even */
+static inline float fetch_tsdf(const Raycaster* rc, float px, float py, float pz, uint64_t* fetches)
+{
+  const int x = clampi((int)nearbyintf(px * rc->ivx), rc->X - 1);
+  const int y = clampi((int)nearbyintf(py * rc->ivy), rc->Y - 1);
+  const int z = clampi((int)nearbyintf(pz * rc->ivz), rc->Z - 1);
+  ++*fetches;
+  return voxel_tsdf(rc, x, y, z);
+}
+
+/* cu:167-192  trilinear; the argument is already in voxel units */
+static float interpolate(const Raycaster* rc, float cfx, float cfy, float cfz)
+{
+  const float fx = floorf(cfx), fy = floorf(cfy), fz = floorf(cfz);
+  /* compare in float first so that NaN / huge values cannot reach the int conversion */
+  if (!(fx >= 0.f && fx < (float)(rc->X - 1) && fy >= 0.f && fy < (float)(rc->Y - 1) && fz >= 0.f && fz < (float)(rc->Z - 1)))
+    return NAN;
+  const int gx = (int)fx, gy = (int)fy, gz = (int)fz;
+  const float a = cfx - (float)gx, b = cfy - (float)gy, c = cfz - (float)gz;
+  float tsdf = 0.f;
+  tsdf += voxel_tsdf(rc, gx + 0, gy + 0, gz + 0) * (1 - a) * (1 - b) * (1 - c);
+  tsdf += voxel_tsdf(rc, gx + 0, gy + 0, gz + 1) * (1 - a) * (1 - b) * c;
+  tsdf += voxel_tsdf(rc, gx + 0, gy + 1, gz + 0) * (1 - a) * b * (1 - c);
+  tsdf += voxel_tsdf(rc, gx + 0, gy + 1, gz + 1) * (1 - a) * b * c;
+  tsdf += voxel_tsdf(rc, gx + 1, gy + 0, gz + 0) * a * (1 - b) * (1 - c);
+  tsdf += voxel_tsdf(rc, gx + 1, gy + 0, gz + 1) * a * (1 - b) * c;
+  tsdf += voxel_tsdf(rc, gx + 1, gy + 1, gz + 0) * a * b * (1 - c);
+  tsdf += voxel_tsdf(rc, gx + 1, gy + 1, gz + 1) * a * b * c;
+  return tsdf;
+}
+
+/* temp_utils.hpp:103  v * rsqrt(dot(v, v)) */
+static inline void normalize3(float* x, float* y, float* z)
+{
+  const float s = 1.0f / sqrtf(dot3(*x, *y, *z, *x, *y, *z));
+  *x *= s;
+  *y *= s;
+  *z *= s;
+}
+
+/* cu:354-372 */
+static void compute_normal(const Raycaster* rc, float px, float py, float pz, float n[3])
+{
+  const float Fx1 = interpolate(rc, (px + rc->gdx) * rc->ivx, py * rc->ivy, pz * rc->ivz);
+  const float Fx2 = interpolate(rc, (px - rc->gdx) * rc->ivx, py * rc->ivy, pz * rc->ivz);
+  n[0] = (Fx1 - Fx2) / rc->gdx;
+  const float Fy1 = interpolate(rc, px * rc->ivx, (py + rc->gdy) * rc->ivy, pz * rc->ivz);
+  const float Fy2 = interpolate(rc, px * rc->ivx, (py - rc->gdy) * rc->ivy, pz * rc->ivz);
+  n[1] = (Fy1 - Fy2) / rc->gdy;
+  const float Fz1 = interpolate(rc, px * rc->ivx, py * rc->ivy, (pz + rc->gdz) * rc->ivz);
+  const float Fz2 = interpolate(rc, px * rc->ivx, py * rc->ivy, (pz - rc->gdz) * rc->ivz);
+  n[2] = (Fz1 - Fz2) / rc->gdz;
+  normalize3(&n[0], &n[1], &n[2]);
+}
+
+/* One pixel: cu:288-352 (and :220-285, which differs only in what is stored).
+ * Returns 1 and fills vertex (camera frame) / normal on a hit. */
+static int raycast_pixel(const Raycaster* rc, int x, int y, float vertex[3], float normal[3], uint64_t* fetches)
+{
+  const float* R = rc->R;
+  const float* t = rc->t;
+  /* cu:300-301  ray_dir = normalized(aff.R * reproj(x, y, 1.f));  device.hpp:57-62 */
+  const float z1 = 1.f;
+  const float rx = z1 * ((float)x - rc->cx) * rc->finvx;
+  const float ry = z1 * ((float)y - rc->cy) * rc->finvy;
+  float dx = dot3(R[0], R[1], R[2], rx, ry, z1);
+  float dy = dot3(R[3], R[4], R[5], rx, ry, z1);
+  float dz = dot3(R[6], R[7], R[8], rx, ry, z1);
+  normalize3(&dx, &dy, &dz);
+  const float ox = t[0], oy = t[1], oz = t[2];
+
+  /* cu:306  box_max = volume_size - voxel_size ;  cu:149-165 intersect (box_min = 0) */
+  const float bx = rc->szx - rc->vsx, by = rc->szy - rc->vsy, bz = rc->szz - rc->vsz;
+  const float irx = 1.f / dx, iry = 1.f / dy, irz = 1.f / dz;
+  const float tbx = irx * (0.f - ox), tby = iry * (0.f - oy), tbz = irz * (0.f - oz);
+  const float ttx = irx * (bx - ox), tty = iry * (by - oy), ttz = irz * (bz - oz);
+  const float tmnx = fminf(ttx, tbx), tmny = fminf(tty, tby), tmnz = fminf(ttz, tbz);
+  const float tmxx = fmaxf(ttx, tbx), tmxy = fmaxf(tty, tby), tmxz = fmaxf(ttz, tbz);
+  float tmin = fmaxf(fmaxf(tmnx, tmny), fmaxf(tmnx, tmnz));
+  float tmax = fminf(fminf(tmxx, tmxy), fminf(tmxx, tmxz));
+
+  /* cu:311-314 */
+  tmin = fmaxf(0.f, tmin);
+  if (!(tmin < tmax)) /* 'if (tmin >= tmax) return', and NaN bounds never march */
+    return 0;
+
+  /* cu:316-318 */
+  const float ts = rc->time_step;
+  tmax -= ts;
+  const float sx = dx * ts, sy = dy * ts, sz = dz * ts;
+  float nx = ox + dx * tmin, ny = oy + dy * tmin, nz = oz + dz * tmin;
+
+  /* cu:320-351 */
+  float tsdf_next = fetch_tsdf(rc, nx, ny, nz, fetches);
+  for (float tcurr = tmin; tcurr < tmax; tcurr += ts)
+  {
+    const float tsdf_curr = tsdf_next;
+    const float cxp = nx, cyp = ny, czp = nz;
+    nx += sx;
+    ny += sy;
+    nz += sz;
+    tsdf_next = fetch_tsdf(rc, nx, ny, nz, fetches);
+    if (tsdf_curr < 0.f && tsdf_next > 0.f)
+      return 0;
+    if (tsdf_curr > 0.f && tsdf_next < 0.f)
+    {
+      const float Ft = interpolate(rc, cxp * rc->ivx, cyp * rc->ivy, czp * rc->ivz);
+      const float Ftdt = interpolate(rc, nx * rc->ivx, ny * rc->ivy, nz * rc->ivz);
+      const float Ts = tcurr - (ts * Ft) / (Ftdt - Ft);
+      const float vx = ox + dx * Ts, vy = oy + dy * Ts, vz = oz + dz * Ts;
+      float n[3];
+      compute_normal(rc, vx, vy, vz, n);
+      if (isnan(n[0] * n[1] * n[2]))
+        return 0;
+      const float* Ri = rc->Rinv;
+      normal[0] = dot3(Ri[0], Ri[1], Ri[2], n[0], n[1], n[2]);
+      normal[1] = dot3(Ri[3], Ri[4], Ri[5], n[0], n[1], n[2]);
+      normal[2] = dot3(Ri[6], Ri[7], Ri[8], n[0], n[1], n[2]);
+      const float wx = vx - t[0], wy = vy - t[1], wz = vz - t[2];
+      vertex[0] = dot3(Ri[0], Ri[1], Ri[2], wx, wy, wz);
+      vertex[1] = dot3(Ri[3], Ri[4], Ri[5], wx, wy, wz);
+      vertex[2] = dot3(Ri[6], Ri[7], Ri[8], wx, wy, wz);
+      return 1;
+    }
+  }
+  return 0;
+}
+
+void yko_raycast(const uint32_t* volume, const int dims[3], const float voxel_size[3], float trunc_dist,
+                 const float R[9], const float t[3], const float Rinv[9], const float intr[4],
+                 float raycast_step_factor, float gradient_delta_factor, int rows, int cols, float* points,
+                 size_t points_pitch_bytes, float* normals, size_t normals_pitch_bytes, uint16_t* depth,
+                 size_t depth_pitch_bytes, uint64_t stats[2], int nthreads)
+{
+  Raycaster rc;
+  rc.vol = volume;
+  rc.X = dims[0], rc.Y = dims[1], rc.Z = dims[2];
+  rc.vsx = voxel_size[0], rc.vsy = voxel_size[1], rc.vsz = voxel_size[2];
+  rc.ivx = 1.f / rc.vsx, rc.ivy = 1.f / rc.vsy, rc.ivz = 1.f / rc.vsz;
+  rc.gdx = rc.vsx * gradient_delta_factor, rc.gdy = rc.vsy * gradient_delta_factor, rc.gdz = rc.vsz * gradient_delta_factor;
+  rc.szx = rc.vsx * (float)rc.X, rc.szy = rc.vsy * (float)rc.Y, rc.szz = rc.vsz * (float)rc.Z;
+  rc.time_step = trunc_dist * raycast_step_factor;
+  rc.R = R, rc.t = t, rc.Rinv = Rinv;
+  rc.finvx = 1.f / intr[0], rc.finvy = 1.f / intr[1], rc.cx = intr[2], rc.cy = intr[3];
+
+  uint64_t fetches = 0, hits = 0;
+#ifdef _OPENMP
+  if (nthreads < 1)
+    nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads) reduction(+ : fetches, hits)
+#endif
+  for (int y = 0; y < rows; ++y)
+  {
+    float* prow = points ? (float*)((char*)points + (size_t)y * points_pitch_bytes) : NULL;
+    float* nrow = (float*)((char*)normals + (size_t)y * normals_pitch_bytes);
+    uint16_t* drow = depth ? (uint16_t*)((char*)depth + (size_t)y * depth_pitch_bytes) : NULL;
+    for (int x = 0; x < cols; ++x)
+    {
+      float v[3], n[3];
+      const int hit = raycast_pixel(&rc, x, y, v, n, &fetches);
+      hits += (uint64_t)hit;
+      if (hit)
+      {
+        nrow[4 * x + 0] = n[0], nrow[4 * x + 1] = n[1], nrow[4 * x + 2] = n[2], nrow[4 * x + 3] = 0.f;
+        if (prow)
+          prow[4 * x + 0] = v[0], prow[4 * x + 1] = v[1], prow[4 * x + 2] = v[2], prow[4 * x + 3] = 0.f;
+        if (drow)
+        { /* cu:280  static_cast<ushort>(vertex.z * 1000): truncation; saturating as the GPU conversion does */
+          const float mm = v[2] * 1000.f;
+          drow[x] = (uint16_t)(mm >= 65535.f ? 65535 : (mm > 0.f ? (int)mm : 0));
+        }
+      }
+      else
+      {
+        nrow[4 * x + 0] = nrow[4 * x + 1] = nrow[4 * x + 2] = nrow[4 * x + 3] = NAN;
+        if (prow)
+          prow[4 * x + 0] = prow[4 * x + 1] = prow[4 * x + 2] = prow[4 * x + 3] = NAN;
+        if (drow)
+          drow[x] = 0;
+      }
+    }
+  }
+  if (stats)
+  {
+    stats[0] += fetches;
+    stats[1] += hits;
+  }
+}
+
 int yko_max_threads(void)
 {
 #ifdef _OPENMP

@@ -61,6 +61,28 @@ void yko_integrate(uint32_t* slab, const int dims[3], int z0, int z1, const floa
                    int max_weight, const uint16_t* dists, size_t dists_pitch_bytes, int rows, int cols,
                    const float R[9], const float t[3], const float intr[4], uint64_t stats[2], int nthreads);
 
+/*
+ * ---- src/cuda/tsdf_volume.cu:149-425 (intersect, interpolate, TsdfRaycaster, device::raycast) ----
+ *
+ * One ray per pixel from the camera through the volume (whole volume, dims[0..2]).
+ * R, t = cam2vol (row-major R); Rinv = the inverse rotation the host forms
+ * (tsdf_volume.cpp:117,136) -- an INPUT here, as it is for the device function.
+ * intr = {fx, fy, cx, cy}; finv = 1/f is formed as in precomp.cpp:73-76.
+ * points / normals: rows x cols float4, row pitch in bytes; depth (u16 mm) may be given instead of
+ * points (the Depth overload, tsdf_volume.cu:220-285): pass the one wanted, NULL for the other.
+ * Pixels without a hit hold quiet NaN x4 (points, normals) or 0 (depth).
+ * rsqrt (temp_utils.hpp:103) -> 1.0f / sqrtf;  __fdividef -> '/';  __float2int_rn -> nearbyintf
+ * (RNE); __float2int_rd -> floorf.  No FMA contraction (C semantics; nvcc's -fmad is unpinned).
+ * fetch_tsdf (cu:210-217) has no bounds test in the reference; indices are clamped to the volume
+ * here, which changes nothing wherever the reference's read is defined.
+ * stats (may be NULL): stats[0] += nearest-voxel fetches, stats[1] += pixels with a hit.
+ */
+void yko_raycast(const uint32_t* volume, const int dims[3], const float voxel_size[3], float trunc_dist,
+                 const float R[9], const float t[3], const float Rinv[9], const float intr[4],
+                 float raycast_step_factor, float gradient_delta_factor, int rows, int cols, float* points,
+                 size_t points_pitch_bytes, float* normals, size_t normals_pitch_bytes, uint16_t* depth,
+                 size_t depth_pitch_bytes, uint64_t stats[2], int nthreads);
+
 int yko_max_threads(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Times yakhip_raycast_points on a 512^3 volume fused from the S2 orbit scene (GPU only; no oracle).
+Usage: python tools/bench_raycast.py [--n 512] [--reps 20]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=512)
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    import torch
+
+    from yak_amd import capi, synth
+
+    ctx = capi.Context(0)
+    n = args.n
+    dims, vs, tr = synth.volume_geometry(n)
+    vol = torch.zeros(n ** 3, dtype=torch.int32, device="cuda")
+    desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT)
+    d_dists = torch.empty((synth.ROWS, synth.COLS), dtype=torch.int16, device="cuda")
+    for f in range(0, 300, 15):
+        depth, R, t = synth.scene_s2(f)
+        d_depth = torch.from_numpy(depth.view(np.int16)).cuda()
+        ctx.compute_dists(d_depth.data_ptr(), synth.COLS * 2, d_dists.data_ptr(), synth.COLS * 2, synth.ROWS, synth.COLS,
+                          synth.INTR)
+        ctx.integrate(desc, d_dists.data_ptr(), synth.COLS * 2, synth.ROWS, synth.COLS, R.reshape(-1), t, synth.INTR)
+    torch.cuda.synchronize()
+    pts = torch.empty((synth.ROWS, synth.COLS, 4), dtype=torch.float32, device="cuda")
+    nrm = torch.empty_like(pts)
+    for view in (0, 37, 100, 222):
+        _, R_v2c, t_v2c = synth.scene_s2(view)
+        R = np.ascontiguousarray(R_v2c.T)
+        t = (-(R_v2c.astype(np.float64).T @ t_v2c.astype(np.float64))).astype(np.float32)
+        call = lambda: ctx.raycast_points(desc, R.reshape(-1), t, R_v2c.reshape(-1), synth.INTR, pts.data_ptr(),  # noqa: E731
+                                          synth.COLS * 16, nrm.data_ptr(), synth.COLS * 16, synth.ROWS, synth.COLS)
+        for _ in range(3):
+            call()
+        ctx.set_option("kernel_timing", 1)
+        for _ in range(args.reps):
+            call()
+        ms, k = ctx.kernel_time()
+        ctx.set_option("kernel_timing", 0)
+        hits = int((~torch.isnan(pts[..., 0])).sum().item())
+        print("view %3d: raycast_kernel %.4f ms (mean of %d), %d hits of %d rays" % (view, ms / k, k, hits,
+                                                                                  synth.ROWS * synth.COLS), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,6 +17,7 @@ EXPORTS = [
     "yakhip_malloc", "yakhip_malloc_pitch", "yakhip_free", "yakhip_upload", "yakhip_download",
     "yakhip_upload_2d", "yakhip_download_2d",
     "yakhip_clear_volume", "yakhip_compute_dists", "yakhip_integrate",
+    "yakhip_raycast_points", "yakhip_raycast_depth",
 ]
 
 
@@ -75,6 +76,8 @@ def load():
         "yakhip_clear_volume": [vp, volp],
         "yakhip_compute_dists": [vp, vp, sz, vp, sz, i, i, fp],
         "yakhip_integrate": [vp, volp, vp, sz, i, i, fp, fp, fp],
+        "yakhip_raycast_points": [vp, volp, fp, fp, fp, fp, C.c_float, C.c_float, vp, sz, vp, sz, i, i],
+        "yakhip_raycast_depth": [vp, volp, fp, fp, fp, fp, C.c_float, C.c_float, vp, sz, vp, sz, i, i],
     }
     for name, argtypes in sigs.items():
         fn = getattr(L, name)
@@ -160,6 +163,18 @@ class Context:
     def integrate(self, vol, dists_ptr, dists_pitch, rows, cols, R, t, intr):
         _chk(load().yakhip_integrate(self._h, C.byref(vol), C.c_void_p(dists_ptr), dists_pitch, rows, cols,
                                      _f32(R, 9), _f32(t, 3), _f32(intr, 4)))
+
+    def raycast_points(self, vol, R, t, Rinv, intr, points_ptr, points_pitch, normals_ptr, normals_pitch, rows, cols,
+                       step_factor=0.75, gradient_delta_factor=0.5):
+        _chk(load().yakhip_raycast_points(self._h, C.byref(vol), _f32(R, 9), _f32(t, 3), _f32(Rinv, 9), _f32(intr, 4),
+                                          step_factor, gradient_delta_factor, C.c_void_p(points_ptr), points_pitch,
+                                          C.c_void_p(normals_ptr), normals_pitch, rows, cols))
+
+    def raycast_depth(self, vol, R, t, Rinv, intr, depth_ptr, depth_pitch, normals_ptr, normals_pitch, rows, cols,
+                      step_factor=0.75, gradient_delta_factor=0.5):
+        _chk(load().yakhip_raycast_depth(self._h, C.byref(vol), _f32(R, 9), _f32(t, 3), _f32(Rinv, 9), _f32(intr, 4),
+                                         step_factor, gradient_delta_factor, C.c_void_p(depth_ptr), depth_pitch,
+                                         C.c_void_p(normals_ptr), normals_pitch, rows, cols))
 
 
 def volume_desc(data_ptr, dims, voxel_size, trunc_dist, max_weight, z0=0, z1=None):

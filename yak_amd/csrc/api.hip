@@ -27,6 +27,27 @@ int check(hipError_t e, const char* what)
   return (int)e;
 }
 
+int timing_begin(yakhip_ctx* ctx, std::pair<hipEvent_t, hipEvent_t>** ev)
+{
+  *ev = nullptr;
+  if (!ctx->kernel_timing)
+    return 0;
+  if (ctx->timing_used == ctx->timing_events.size())
+  {
+    std::pair<hipEvent_t, hipEvent_t> e;
+    YAKHIP_TRY(hipEventCreate(&e.first));
+    YAKHIP_TRY(hipEventCreate(&e.second));
+    ctx->timing_events.push_back(e);
+  }
+  *ev = &ctx->timing_events[ctx->timing_used++];
+  return check(hipEventRecord((*ev)->first, ctx->stream), "hipEventRecord");
+}
+
+int timing_end(yakhip_ctx* ctx, std::pair<hipEvent_t, hipEvent_t>* ev)
+{
+  return ev ? check(hipEventRecord(ev->second, ctx->stream), "hipEventRecord") : 0;
+}
+
 // Makes the context's device current for the calling thread.
 static int enter(const yakhip_ctx* ctx)
 {
@@ -429,6 +450,73 @@ int yakhip_integrate(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dist
   p.cx = intr[2];
   p.cy = intr[3];
   return launch_integrate(ctx, p);
+}
+
+static int raycast_common(yakhip_ctx* ctx, const yakhip_volume* vol, const float R[9], const float t[3],
+                          const float Rinv[9], const float intr[4], float step_factor, float gradient_delta_factor,
+                          void* points, size_t points_pitch, void* depth, size_t depth_pitch, void* normals,
+                          size_t normals_pitch, int rows, int cols)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_volume(vol)) != 0)
+    return rc;
+  if (vol->z0 != 0 || vol->z1 != vol->dims[2])
+    return fail(YAKHIP_EINVAL, "raycast: needs the whole volume, got the slab [%d, %d) of %d layers", vol->z0, vol->z1,
+                vol->dims[2]);
+  if (!R || !t || !Rinv || !intr)
+    return fail(YAKHIP_EINVAL, "raycast: null pose or intrinsics");
+  if (!(vol->trunc_dist > 0.f) || !(step_factor > 0.f) || !(gradient_delta_factor > 0.f))
+    return fail(YAKHIP_EINVAL, "raycast: trunc_dist, step factor and gradient delta factor must be positive");
+  if ((rc = check_image("raycast(normals)", normals, normals_pitch, rows, cols, 16)) != 0)
+    return rc;
+  if (points && (rc = check_image("raycast(points)", points, points_pitch, rows, cols, 16)) != 0)
+    return rc;
+  if (depth && (rc = check_image("raycast(depth)", depth, depth_pitch, rows, cols, 2)) != 0)
+    return rc;
+
+  RaycastParams p;
+  p.vol = (const uint32_t*)vol->data;
+  p.X = vol->dims[0], p.Y = vol->dims[1], p.Z = vol->dims[2];
+  p.vsx = vol->voxel_size[0], p.vsy = vol->voxel_size[1], p.vsz = vol->voxel_size[2];
+  // tsdf_volume.cu:399-402 (host arithmetic of device::raycast), :306 (box_max)
+  p.ivx = 1.f / p.vsx, p.ivy = 1.f / p.vsy, p.ivz = 1.f / p.vsz;
+  p.gdx = p.vsx * gradient_delta_factor, p.gdy = p.vsy * gradient_delta_factor, p.gdz = p.vsz * gradient_delta_factor;
+  p.bx = p.vsx * (float)p.X - p.vsx, p.by = p.vsy * (float)p.Y - p.vsy, p.bz = p.vsz * (float)p.Z - p.vsz;
+  p.time_step = vol->trunc_dist * step_factor;
+  memcpy(p.R, R, sizeof(p.R));
+  memcpy(p.t, t, sizeof(p.t));
+  memcpy(p.Rinv, Rinv, sizeof(p.Rinv));
+  p.finvx = 1.f / intr[0], p.finvy = 1.f / intr[1];  // precomp.cpp:73-76
+  p.cx = intr[2], p.cy = intr[3];
+  p.rows = rows, p.cols = cols;
+  p.points = (uint8_t*)points, p.normals = (uint8_t*)normals, p.depth = (uint8_t*)depth;
+  p.points_pitch = (uint32_t)points_pitch, p.normals_pitch = (uint32_t)normals_pitch;
+  p.depth_pitch = (uint32_t)depth_pitch;
+  return launch_raycast(ctx, p);
+}
+
+int yakhip_raycast_points(yakhip_ctx* ctx, const yakhip_volume* vol, const float R[9], const float t[3],
+                          const float Rinv[9], const float intr[4], float step_factor, float gradient_delta_factor,
+                          void* points_dev, size_t points_pitch, void* normals_dev, size_t normals_pitch, int rows,
+                          int cols)
+{
+  if (!points_dev)
+    return fail(YAKHIP_EINVAL, "raycast(points): null image pointer");
+  return raycast_common(ctx, vol, R, t, Rinv, intr, step_factor, gradient_delta_factor, points_dev, points_pitch,
+                        nullptr, 0, normals_dev, normals_pitch, rows, cols);
+}
+
+int yakhip_raycast_depth(yakhip_ctx* ctx, const yakhip_volume* vol, const float R[9], const float t[3],
+                         const float Rinv[9], const float intr[4], float step_factor, float gradient_delta_factor,
+                         void* depth_dev, size_t depth_pitch, void* normals_dev, size_t normals_pitch, int rows,
+                         int cols)
+{
+  if (!depth_dev)
+    return fail(YAKHIP_EINVAL, "raycast(depth): null image pointer");
+  return raycast_common(ctx, vol, R, t, Rinv, intr, step_factor, gradient_delta_factor, nullptr, 0, depth_dev,
+                        depth_pitch, normals_dev, normals_pitch, rows, cols);
 }
 
 }  // extern "C"

@@ -591,24 +591,15 @@ static int launch_variant(yakhip_ctx* ctx, const IntegrateParams& p, dim3 grid)
 {
   const size_t lds = VX == 4 && p.grp_enable ? (size_t)p.cw * p.ch * sizeof(float) : 0;
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-  if (ctx->kernel_timing)  // measurement aid: one event pair around this kernel only
-  {
-    if (ctx->timing_used == ctx->timing_events.size())
-    {
-      std::pair<hipEvent_t, hipEvent_t> e;
-      YAKHIP_TRY(hipEventCreate(&e.first));
-      YAKHIP_TRY(hipEventCreate(&e.second));
-      ctx->timing_events.push_back(e);
-    }
-    ev = &ctx->timing_events[ctx->timing_used++];
-    YAKHIP_TRY(hipEventRecord(ev->first, ctx->stream));
-  }
+  int rc = timing_begin(ctx, &ev);  // measurement aid: one event pair around this kernel only
+  if (rc != 0)
+    return rc;
   if (ctx->nontemporal)
     hipLaunchKernelGGL((integrate_kernel<VX, true>), grid, dim3(256), lds, ctx->stream, p);
   else
     hipLaunchKernelGGL((integrate_kernel<VX, false>), grid, dim3(256), lds, ctx->stream, p);
-  if (ev)
-    YAKHIP_TRY(hipEventRecord(ev->second, ctx->stream));
+  if ((rc = timing_end(ctx, ev)) != 0)
+    return rc;
   return check(hipGetLastError(), "integrate_kernel launch");
 }
 

@@ -35,6 +35,11 @@ int fail(int code, const char* fmt, ...);
 // hipError -> return code (0 stays 0); records file/line text on failure.
 int check(hipError_t e, const char* what);
 
+// "kernel_timing" option: bracket the dominant kernel of a call with an event pair on the context's
+// stream.  begin() hands back nullptr when the option is off; end(nullptr) is a no-op.
+int timing_begin(yakhip_ctx* ctx, std::pair<hipEvent_t, hipEvent_t>** ev);
+int timing_end(yakhip_ctx* ctx, std::pair<hipEvent_t, hipEvent_t>* ev);
+
 #define YAKHIP_TRY(expr)                                   \
   do                                                       \
   {                                                        \
@@ -69,7 +74,27 @@ struct IntegrateParams
   float fx, fy, cx, cy;
 };
 
+// Ray casting (raycast.hip).  Everything wave-uniform travels in the kernarg segment.
+struct RaycastParams
+{
+  const uint32_t* vol;  // whole volume, layer 0
+  int X, Y, Z;
+  float vsx, vsy, vsz;  // voxel_size
+  float ivx, ivy, ivz;  // 1 / voxel_size            (tsdf_volume.cu:402)
+  float gdx, gdy, gdz;  // voxel_size * grad factor  (tsdf_volume.cu:401)
+  float bx, by, bz;     // box_max = voxel_size * dims - voxel_size  (tsdf_volume.cu:399, 306)
+  float time_step;      // trunc_dist * step factor  (tsdf_volume.cu:400)
+  float R[9], t[3], Rinv[9];
+  float finvx, finvy, cx, cy;
+  int rows, cols;
+  uint8_t* points;      // float4 image or nullptr
+  uint8_t* normals;     // float4 image
+  uint8_t* depth;       // uint16 image or nullptr
+  uint32_t points_pitch, normals_pitch, depth_pitch;
+};
+
 int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p);
+int launch_raycast(yakhip_ctx* ctx, const RaycastParams& p);
 int launch_clear(const yakhip_ctx* ctx, uint32_t* data, size_t n_voxels);
 int launch_selftest_division(yakhip_ctx* ctx, unsigned long long counts[4]);
 int launch_compute_dists(const yakhip_ctx* ctx, const uint8_t* depth, size_t depth_pitch, uint8_t* dists,
