@@ -156,6 +156,49 @@ int yakhip_raycast_depth(yakhip_ctx* ctx, const yakhip_volume* vol, const float 
                          void* depth_dev, size_t depth_pitch, void* normals_dev, size_t normals_pitch, int rows,
                          int cols);
 
+/* ---- tracking side: depth pre-processing and projective ICP ------------
+ * Depth images: uint16 millimetres; point / normal maps: float4 {x, y, z, w}, NaN = no data.  All
+ * row-pitched (pitch in bytes; multiple of 2 resp. 16). */
+
+/* Replaces kfusion::device::bilateralFilter (internal.hpp:146; yak/src/cuda/imgproc.cu:10-56).
+ * sigma_depth in metres, sigma_spatial and kernel_size in pixels.  src != dst. */
+int yakhip_bilateral_filter(yakhip_ctx* ctx, const void* src_dev, size_t src_pitch, void* dst_dev, size_t dst_pitch,
+                            int rows, int cols, int kernel_size, float sigma_spatial, float sigma_depth);
+/* Replaces kfusion::device::truncateDepth (imgproc.cu:66-85): depth > max_dist (metres) -> 0, in place. */
+int yakhip_truncate_depth(yakhip_ctx* ctx, void* depth_dev, size_t depth_pitch, int rows, int cols, float max_dist);
+/* Replaces kfusion::device::depthPyr (imgproc.cu:94-136): dst is (src_rows / 2) x (src_cols / 2). */
+int yakhip_depth_pyramid(yakhip_ctx* ctx, const void* src_dev, size_t src_pitch, int src_rows, int src_cols,
+                         void* dst_dev, size_t dst_pitch, float sigma_depth);
+/* Replaces kfusion::device::computePointNormals (internal.hpp:160; imgproc.cu:210-250):
+ * back-projects every pixel and takes the normal of the triangle (x,y), (x+1,y), (x,y+1).
+ * intr = the intrinsics of THIS pyramid level (Intr::operator()(level), yak/src/kfusion/precomp.cpp:10-14). */
+int yakhip_compute_points_normals(yakhip_ctx* ctx, const float intr[4], const void* depth_dev, size_t depth_pitch,
+                                  int rows, int cols, void* points_dev, size_t points_pitch, void* normals_dev,
+                                  size_t normals_pitch);
+/* Replaces kfusion::device::resizePointsNormals (internal.hpp:157; imgproc.cu:348-394): 2 x 2 box
+ * average where all four points exist; outputs are (src_rows / 2) x (src_cols / 2). */
+int yakhip_resize_points_normals(yakhip_ctx* ctx, const void* points_dev, size_t points_pitch, const void* normals_dev,
+                                 size_t normals_pitch, int src_rows, int src_cols, void* points_out_dev,
+                                 size_t points_out_pitch, void* normals_out_dev, size_t normals_out_pitch);
+/* Replaces kfusion::device::ComputeIcpHelper::operator() (Points overload, internal.hpp:113;
+ * yak/src/cuda/proj_icp.cu:74-102, 105-387, 416-439) together with the stream synchronisation of
+ * StreamHelper::get (yak/src/kfusion/projective_icp.cpp:42-61): BLOCKING.  For the pose estimate R,t
+ * (current -> previous camera) it finds the projective correspondence of every pixel of vcurr in
+ * vprev, rejects by distance / normal angle, and returns
+ *   sums_host[27]  = sum of row[i] * row[j], i <= j < 7, i < 6, row = [cross(s, n), n, n.(d - s)],
+ *                    in the order StreamHelper::get unpacks (upper triangle of A row by row, b interleaved);
+ *   counts_host[6] = pixels accepted, rejected as 40 (no source point), 80 (behind / outside the image),
+ *                    120 (no destination point), 160 (too far), 200 (normals disagree); may be NULL
+ *                    (no counterpart in the reference; its mask output is commented out, proj_icp.cu:350).
+ * intr = LEVEL-0 intrinsics, divided by 1 << level as setLevelIntr does (projective_icp.cpp:16-22);
+ * dist_thres in metres, angle_thres in radians (ComputeIcpHelper ctor, projective_icp.cpp:10-14).
+ * The additions are done in a fixed order: the result is the same on every run. */
+int yakhip_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], int level,
+                          float dist_thres, float angle_thres, const void* vcurr_dev, size_t vcurr_pitch,
+                          const void* ncurr_dev, size_t ncurr_pitch, const void* vprev_dev, size_t vprev_pitch,
+                          const void* nprev_dev, size_t nprev_pitch, int rows, int cols, float sums_host[27],
+                          int counts_host[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,20 @@ def lib():
         L.yko_raycast.argtypes = [_u32p, _i32p, _f32p, C.c_float, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_float,
                                   C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                   C.c_size_t, _u64p, C.c_int]
+        vp, sz, i, f = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+        L.yko_bilateral_filter.restype = None
+        L.yko_bilateral_filter.argtypes = [vp, sz, vp, sz, i, i, i, f, f]
+        L.yko_truncate_depth.restype = None
+        L.yko_truncate_depth.argtypes = [vp, sz, i, i, f]
+        L.yko_depth_pyramid.restype = None
+        L.yko_depth_pyramid.argtypes = [vp, sz, i, i, vp, sz, f]
+        L.yko_compute_points_normals.restype = None
+        L.yko_compute_points_normals.argtypes = [vp, sz, i, i, _f32p, vp, sz, vp, sz]
+        L.yko_resize_points_normals.restype = None
+        L.yko_resize_points_normals.argtypes = [vp, sz, vp, sz, i, i, vp, sz, vp, sz]
+        L.yko_icp_accumulate.restype = None
+        L.yko_icp_accumulate.argtypes = [_f32p, _f32p, _f32p, i, f, f, vp, sz, vp, sz, vp, sz, vp, sz, i, i,
+                                         np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), _u64p, vp]
         L.yko_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -154,6 +168,80 @@ def raycast(volume, dims, voxel_size, trunc_dist, R, t, Rinv, intr, rows, cols, 
         points.ctypes.data if points is not None else None, cols * 16, normals.ctypes.data, cols * 16,
         depth.ctypes.data if depth is not None else None, cols * 2, stats, int(nthreads))
     return (depth if want_depth else points), normals, int(stats[0]), int(stats[1])
+
+
+def _u16img(a):
+    a = np.ascontiguousarray(a, dtype=np.uint16)
+    assert a.ndim == 2
+    return a
+
+
+def _f4img(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 3 and a.shape[2] == 4
+    return a
+
+
+def bilateral_filter(depth, kernel_size=7, sigma_spatial=4.5, sigma_depth=0.04):
+    src = _u16img(depth)
+    rows, cols = src.shape
+    dst = np.empty_like(src)
+    lib().yko_bilateral_filter(src.ctypes.data, cols * 2, dst.ctypes.data, cols * 2, rows, cols, int(kernel_size),
+                               float(sigma_spatial), float(sigma_depth))
+    return dst
+
+
+def truncate_depth(depth, max_dist):
+    out = _u16img(depth).copy()
+    rows, cols = out.shape
+    lib().yko_truncate_depth(out.ctypes.data, cols * 2, rows, cols, float(max_dist))
+    return out
+
+
+def depth_pyramid(depth, sigma_depth=0.04):
+    src = _u16img(depth)
+    rows, cols = src.shape
+    dst = np.empty((rows // 2, cols // 2), dtype=np.uint16)
+    lib().yko_depth_pyramid(src.ctypes.data, cols * 2, rows, cols, dst.ctypes.data, (cols // 2) * 2, float(sigma_depth))
+    return dst
+
+
+def compute_points_normals(depth, intr):
+    """intr = the intrinsics of this pyramid level.  Returns (points, normals), each (rows, cols, 4) float32."""
+    src = _u16img(depth)
+    rows, cols = src.shape
+    pts = np.empty((rows, cols, 4), dtype=np.float32)
+    nrm = np.empty_like(pts)
+    lib().yko_compute_points_normals(src.ctypes.data, cols * 2, rows, cols,
+                                     np.ascontiguousarray(intr, dtype=np.float32), pts.ctypes.data, cols * 16,
+                                     nrm.ctypes.data, cols * 16)
+    return pts, nrm
+
+
+def resize_points_normals(points, normals):
+    p, n = _f4img(points), _f4img(normals)
+    rows, cols = p.shape[:2]
+    po = np.empty((rows // 2, cols // 2, 4), dtype=np.float32)
+    no = np.empty_like(po)
+    lib().yko_resize_points_normals(p.ctypes.data, cols * 16, n.ctypes.data, cols * 16, rows, cols, po.ctypes.data,
+                                    (cols // 2) * 16, no.ctypes.data, (cols // 2) * 16)
+    return po, no
+
+
+def icp_accumulate(R, t, intr, level, dist_thres, angle_thres, vcurr, ncurr, vprev, nprev, want_codes=False):
+    """Returns (sums float64[27], counts uint64[6][, codes uint8 (rows, cols)])."""
+    vc, nc, vp_, np_ = _f4img(vcurr), _f4img(ncurr), _f4img(vprev), _f4img(nprev)
+    rows, cols = vc.shape[:2]
+    assert nc.shape == vc.shape == vp_.shape == np_.shape
+    sums = np.zeros(27, dtype=np.float64)
+    counts = np.zeros(6, dtype=np.uint64)
+    codes = np.zeros((rows, cols), dtype=np.uint8) if want_codes else None
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32).reshape(-1)  # noqa: E731
+    lib().yko_icp_accumulate(f32(R), f32(t), f32(intr), int(level), float(dist_thres), float(angle_thres),
+                             vc.ctypes.data, cols * 16, nc.ctypes.data, cols * 16, vp_.ctypes.data, cols * 16,
+                             np_.ctypes.data, cols * 16, rows, cols, sums, counts,
+                             codes.ctypes.data if codes is not None else None)
+    return (sums, counts, codes) if want_codes else (sums, counts)
 
 
 def max_threads():

@@ -18,6 +18,7 @@
 #include "yak_oracle.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -469,6 +470,249 @@ void yko_raycast(const uint32_t* volume, const int dims[3], const float voxel_si
     stats[0] += fetches;
     stats[1] += hits;
   }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Depth pre-processing: imgproc.cu.
+ * ------------------------------------------------------------------------------------------ */
+#define U16_AT(base, pitch, y, x) (((const uint16_t*)((const char*)(base) + (size_t)(y) * (pitch)))[x])
+#define F4_AT(base, pitch, y, x) ((const float*)((const char*)(base) + (size_t)(y) * (pitch)) + 4 * (size_t)(x))
+#define F4_OUT(base, pitch, y, x) ((float*)((char*)(base) + (size_t)(y) * (pitch)) + 4 * (size_t)(x))
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+/* int * int as the GPU does it (wraps; differences above 46340 mm would overflow a signed product) */
+static inline int wrap_sq(int d) { return (int)((uint32_t)d * (uint32_t)d); }
+
+void yko_bilateral_filter(const uint16_t* src, size_t src_pitch, uint16_t* dst, size_t dst_pitch, int rows, int cols,
+                          int ksz, float sigma_spatial, float sigma_depth)
+{
+  sigma_depth *= 1000; /* :48 metres -> mm */
+  const float s2 = 0.5f / (sigma_spatial * sigma_spatial), d2 = 0.5f / (sigma_depth * sigma_depth); /* :54 */
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x)
+    {
+      const int value = U16_AT(src, src_pitch, y, x);
+      const int tx = imin(x - ksz / 2 + ksz, cols - 1); /* :20-21 (exclusive bounds, clipped to size - 1) */
+      const int ty = imin(y - ksz / 2 + ksz, rows - 1);
+      float sum1 = 0, sum2 = 0;
+      for (int cy = imax(y - ksz / 2, 0); cy < ty; ++cy)
+        for (int cx = imax(x - ksz / 2, 0); cx < tx; ++cx)
+        {
+          const int depth = U16_AT(src, src_pitch, cy, cx);
+          const float space2 = (float)((x - cx) * (x - cx) + (y - cy) * (y - cy));
+          const float color2 = (float)wrap_sq(value - depth);
+          const float weight = expf(-(space2 * s2 + color2 * d2));
+          sum1 += (float)depth * weight;
+          sum2 += weight;
+        }
+      const float q = sum1 / sum2;
+      ((uint16_t*)((char*)dst + (size_t)y * dst_pitch))[x] = isnan(q) ? 0 : (uint16_t)(int)nearbyintf(q); /* :41 */
+    }
+}
+
+void yko_truncate_depth(uint16_t* depth, size_t pitch, int rows, int cols, float max_dist_m)
+{
+  const float mm = max_dist_m * 1000.f; /* :83 static_cast<ushort>(max_dist * 1000.f) */
+  const uint16_t max_dist = (uint16_t)(mm >= 65535.f ? 65535 : (mm > 0.f ? (int)mm : 0));
+  for (int y = 0; y < rows; ++y)
+  {
+    uint16_t* row = (uint16_t*)((char*)depth + (size_t)y * pitch);
+    for (int x = 0; x < cols; ++x)
+      if (row[x] > max_dist)
+        row[x] = 0;
+  }
+}
+
+void yko_depth_pyramid(const uint16_t* src, size_t src_pitch, int src_rows, int src_cols, uint16_t* dst,
+                       size_t dst_pitch, float sigma_depth)
+{
+  const float sigma_depth_mult3 = sigma_depth * 1000 * 3; /* :129, :134 */
+  const int rows = src_rows / 2, cols = src_cols / 2;
+  const int D = 5;
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x)
+    {
+      const int center = U16_AT(src, src_pitch, 2 * y, 2 * x);
+      const int tx = imin(2 * x - D / 2 + D, src_cols - 1);
+      const int ty = imin(2 * y - D / 2 + D, src_rows - 1);
+      int sum = 0, count = 0;
+      for (int cy = imax(0, 2 * y - D / 2); cy < ty; ++cy)
+        for (int cx = imax(0, 2 * x - D / 2); cx < tx; ++cx)
+        {
+          const int val = U16_AT(src, src_pitch, cy, cx);
+          if ((float)abs(val - center) < sigma_depth_mult3)
+          {
+            sum += val;
+            ++count;
+          }
+        }
+      ((uint16_t*)((char*)dst + (size_t)y * dst_pitch))[x] = (uint16_t)(count == 0 ? 0 : sum / count);
+    }
+}
+
+/* device.hpp:57-62 */
+static inline void reproj(float finvx, float finvy, float cx, float cy, int u, int v, float z, float out[3])
+{
+  out[0] = z * ((float)u - cx) * finvx;
+  out[1] = z * ((float)v - cy) * finvy;
+  out[2] = z;
+}
+
+void yko_compute_points_normals(const uint16_t* depth, size_t depth_pitch, int rows, int cols, const float intr[4],
+                                float* points, size_t points_pitch, float* normals, size_t normals_pitch)
+{
+  const float finvx = 1.f / intr[0], finvy = 1.f / intr[1], cx = intr[2], cy = intr[3]; /* precomp.cpp:73-76 */
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x)
+    {
+      float* p = F4_OUT(points, points_pitch, y, x);
+      float* n = F4_OUT(normals, normals_pitch, y, x);
+      p[0] = p[1] = p[2] = p[3] = n[0] = n[1] = n[2] = n[3] = NAN; /* :219 */
+      if (x >= cols - 1 || y >= rows - 1)
+        continue;
+      const float z00 = (float)U16_AT(depth, depth_pitch, y, x) * 0.001f;
+      const float z01 = (float)U16_AT(depth, depth_pitch, y, x + 1) * 0.001f;
+      const float z10 = (float)U16_AT(depth, depth_pitch, y + 1, x) * 0.001f;
+      if (z00 * z01 * z10 != 0)
+      {
+        float v00[3], v01[3], v10[3];
+        reproj(finvx, finvy, cx, cy, x, y, z00, v00);
+        reproj(finvx, finvy, cx, cy, x + 1, y, z01, v01);
+        reproj(finvx, finvy, cx, cy, x, y + 1, z10, v10);
+        const float ax = v01[0] - v00[0], ay = v01[1] - v00[1], az = v01[2] - v00[2];
+        const float bx = v10[0] - v00[0], by = v10[1] - v00[1], bz = v10[2] - v00[2];
+        float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx; /* temp_utils.hpp:105-108 */
+        normalize3(&nx, &ny, &nz);
+        n[0] = -nx, n[1] = -ny, n[2] = -nz, n[3] = 0.f;
+        p[0] = v00[0], p[1] = v00[1], p[2] = v00[2], p[3] = 0.f;
+      }
+    }
+}
+
+void yko_resize_points_normals(const float* points, size_t points_pitch, const float* normals, size_t normals_pitch,
+                               int src_rows, int src_cols, float* points_out, size_t points_out_pitch,
+                               float* normals_out, size_t normals_out_pitch)
+{
+  const int rows = src_rows / 2, cols = src_cols / 2;
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x)
+    {
+      float* vo = F4_OUT(points_out, points_out_pitch, y, x);
+      float* no = F4_OUT(normals_out, normals_out_pitch, y, x);
+      vo[0] = vo[1] = vo[2] = no[0] = no[1] = no[2] = NAN; /* :357 */
+      vo[3] = no[3] = 0.f;
+      const int xs = 2 * x, ys = 2 * y;
+      const float* d00 = F4_AT(points, points_pitch, ys + 0, xs + 0);
+      const float* d01 = F4_AT(points, points_pitch, ys + 0, xs + 1);
+      const float* d10 = F4_AT(points, points_pitch, ys + 1, xs + 0);
+      const float* d11 = F4_AT(points, points_pitch, ys + 1, xs + 1);
+      if (!isnan(d00[0] * d01[0] * d10[0] * d11[0]))
+      {
+        const float* n00 = F4_AT(normals, normals_pitch, ys + 0, xs + 0);
+        const float* n01 = F4_AT(normals, normals_pitch, ys + 0, xs + 1);
+        const float* n10 = F4_AT(normals, normals_pitch, ys + 1, xs + 0);
+        const float* n11 = F4_AT(normals, normals_pitch, ys + 1, xs + 1);
+        for (int k = 0; k < 3; ++k)
+        {
+          vo[k] = (d00[k] + d01[k] + d10[k] + d11[k]) * 0.25f;
+          no[k] = (n00[k] + n01[k] + n10[k] + n11[k]) * 0.25f;
+        }
+      }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Projective ICP, one linearisation: proj_icp.cu.
+ * ------------------------------------------------------------------------------------------ */
+void yko_icp_accumulate(const float R[9], const float t[3], const float intr[4], int level, float dist_thres,
+                        float angle_thres, const float* vcurr, size_t vcurr_pitch, const float* ncurr,
+                        size_t ncurr_pitch, const float* vprev, size_t vprev_pitch, const float* nprev,
+                        size_t nprev_pitch, int rows, int cols, double sums[27], uint64_t counts[6], uint8_t* codes)
+{
+  /* projective_icp.cpp:10-22 */
+  const float min_cosine = (float)cos((double)angle_thres);
+  const float dist2_thres = dist_thres * dist_thres;
+  const int div = 1 << level;
+  const float fx = intr[0] / (float)div, fy = intr[1] / (float)div, cx = intr[2] / (float)div, cy = intr[3] / (float)div;
+  const float frows = (float)rows, fcols = (float)cols; /* projective_icp.cpp:200-201 */
+
+  for (int k = 0; k < 27; ++k)
+    sums[k] = 0.0;
+  for (int k = 0; k < 6; ++k)
+    counts[k] = 0;
+
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x)
+    {
+      int code = 0;
+      float row[7] = { 0, 0, 0, 0, 0, 0, 0 };
+      do
+      { /* find_coresp, proj_icp.cu:74-102 */
+        const float* sp = F4_AT(vcurr, vcurr_pitch, y, x);
+        if (isnan(sp[0]))
+        {
+          code = 40;
+          break;
+        }
+        const float sx = dot3(R[0], R[1], R[2], sp[0], sp[1], sp[2]) + t[0];
+        const float sy = dot3(R[3], R[4], R[5], sp[0], sp[1], sp[2]) + t[1];
+        const float sz = dot3(R[6], R[7], R[8], sp[0], sp[1], sp[2]) + t[2];
+        if (sz <= 0)
+        {
+          code = 80;
+          break;
+        }
+        const float coox = fmaf(fx, sx / sz, cx), cooy = fmaf(fy, sy / sz, cy); /* :24-31 */
+        if (!(coox >= 0 && cooy >= 0 && coox < fcols && cooy < frows))
+        {
+          code = 80;
+          break;
+        }
+        const int px = (int)floorf(coox), py = (int)floorf(cooy); /* point-filtered tex2D */
+        const float* dp = F4_AT(vprev, vprev_pitch, py, px);
+        if (isnan(dp[0]))
+        {
+          code = 120;
+          break;
+        }
+        const float ex = sx - dp[0], ey = sy - dp[1], ez = sz - dp[2];
+        if (dot3(ex, ey, ez, ex, ey, ez) > dist2_thres)
+        {
+          code = 160;
+          break;
+        }
+        const float* nc = F4_AT(ncurr, ncurr_pitch, y, x);
+        const float nsx = dot3(R[0], R[1], R[2], nc[0], nc[1], nc[2]);
+        const float nsy = dot3(R[3], R[4], R[5], nc[0], nc[1], nc[2]);
+        const float nsz = dot3(R[6], R[7], R[8], nc[0], nc[1], nc[2]);
+        const float* nd = F4_AT(nprev, nprev_pitch, py, px);
+        const float cosine = fabsf(dot3(nsx, nsy, nsz, nd[0], nd[1], nd[2]));
+        if (cosine < min_cosine)
+        { /* literal: a NaN cosine passes this test and poisons the sums, which makes the caller's
+             determinant NaN and the frame a tracking failure (projective_icp.cpp:217-222) */
+          code = 200;
+          break;
+        }
+        /* :354-359  row = [cross(s, n), n, dot(n, d - s)] */
+        row[0] = sy * nd[2] - sz * nd[1];
+        row[1] = sz * nd[0] - sx * nd[2];
+        row[2] = sx * nd[1] - sy * nd[0];
+        row[3] = nd[0], row[4] = nd[1], row[5] = nd[2];
+        row[6] = dot3(nd[0], nd[1], nd[2], dp[0] - sx, dp[1] - sy, dp[2] - sz);
+      } while (0);
+
+      if (codes)
+        codes[(size_t)y * (size_t)cols + (size_t)x] = (uint8_t)code;
+      counts[code / 40] += 1;
+      if (code == 0)
+      {
+        int k = 0;
+        for (int i = 0; i < 6; ++i)
+          for (int j = i; j < 7; ++j)
+            sums[k++] += (double)(row[i] * row[j]); /* the product is formed in fp32, cu:122-335 */
+      }
+    }
 }
 
 int yko_max_threads(void)

@@ -83,6 +83,43 @@ void yko_raycast(const uint32_t* volume, const int dims[3], const float voxel_si
                  size_t points_pitch_bytes, float* normals, size_t normals_pitch_bytes, uint16_t* depth,
                  size_t depth_pitch_bytes, uint64_t stats[2], int nthreads);
 
+/* ---- pre-processing of the depth frame for ICP: src/cuda/imgproc.cu ------------------------- */
+
+/* imgproc.cu:10-56 (bilateral_kernel + device::bilateralFilter).  sigma_depth in metres (scaled to mm
+ * as :48 does).  __expf -> expf: the u16 result may differ from a GPU's by 1 where the quotient
+ * sits next to a rounding boundary; tests allow exactly that.  __float2int_rn -> RNE, NaN -> 0. */
+void yko_bilateral_filter(const uint16_t* src, size_t src_pitch_bytes, uint16_t* dst, size_t dst_pitch_bytes, int rows,
+                          int cols, int kernel_size, float sigma_spatial, float sigma_depth);
+/* imgproc.cu:66-85 */
+void yko_truncate_depth(uint16_t* depth, size_t pitch_bytes, int rows, int cols, float max_dist_m);
+/* imgproc.cu:94-136: dst is (src_rows/2) x (src_cols/2) (imgproc.cpp:15-19) */
+void yko_depth_pyramid(const uint16_t* src, size_t src_pitch_bytes, int src_rows, int src_cols, uint16_t* dst,
+                       size_t dst_pitch_bytes, float sigma_depth);
+/* imgproc.cu:210-250: points/normals are rows x cols float4 */
+void yko_compute_points_normals(const uint16_t* depth, size_t depth_pitch_bytes, int rows, int cols,
+                                const float intr[4], float* points, size_t points_pitch_bytes, float* normals,
+                                size_t normals_pitch_bytes);
+/* imgproc.cu:348-394: outputs are (src_rows/2) x (src_cols/2) (imgproc.cpp:65-80) */
+void yko_resize_points_normals(const float* points, size_t points_pitch_bytes, const float* normals,
+                               size_t normals_pitch_bytes, int src_rows, int src_cols, float* points_out,
+                               size_t points_out_pitch_bytes, float* normals_out, size_t normals_out_pitch_bytes);
+
+/*
+ * ---- projective ICP, one linearisation: src/cuda/proj_icp.cu:24-39, 74-102, 343-364 (Points path;
+ *      USE_DEPTH is not defined, internal.hpp:8) + projective_icp.cpp:10-22 ----
+ * R,t = the current estimate (curr -> prev camera), intr = level-0 intrinsics, level = pyramid level
+ * (setLevelIntr divides by 1 << level).  sums[27] = sum over accepted pixels of row[i]*row[j], i <= j < 7,
+ * i < 6, in the order of proj_icp.cu:122-335 (what StreamHelper::get unpacks, projective_icp.cpp:42-61),
+ * accumulated in DOUBLE (the reference's float tree order is a schedule, not a specification).
+ * counts[6] = pixels accepted, then rejected with code 40, 80, 120, 160, 200 (cu:78-101).
+ * codes (may be NULL): rows x cols bytes, the per-pixel code.
+ */
+void yko_icp_accumulate(const float R[9], const float t[3], const float intr[4], int level, float dist_thres,
+                        float angle_thres, const float* vcurr, size_t vcurr_pitch_bytes, const float* ncurr,
+                        size_t ncurr_pitch_bytes, const float* vprev, size_t vprev_pitch_bytes, const float* nprev,
+                        size_t nprev_pitch_bytes, int rows, int cols, double sums[27], uint64_t counts[6],
+                        uint8_t* codes);
+
 int yko_max_threads(void);
 
 #ifdef __cplusplus

@@ -18,6 +18,8 @@ EXPORTS = [
     "yakhip_upload_2d", "yakhip_download_2d",
     "yakhip_clear_volume", "yakhip_compute_dists", "yakhip_integrate",
     "yakhip_raycast_points", "yakhip_raycast_depth",
+    "yakhip_bilateral_filter", "yakhip_truncate_depth", "yakhip_depth_pyramid", "yakhip_compute_points_normals",
+    "yakhip_resize_points_normals", "yakhip_icp_accumulate",
 ]
 
 
@@ -78,6 +80,13 @@ def load():
         "yakhip_integrate": [vp, volp, vp, sz, i, i, fp, fp, fp],
         "yakhip_raycast_points": [vp, volp, fp, fp, fp, fp, C.c_float, C.c_float, vp, sz, vp, sz, i, i],
         "yakhip_raycast_depth": [vp, volp, fp, fp, fp, fp, C.c_float, C.c_float, vp, sz, vp, sz, i, i],
+        "yakhip_bilateral_filter": [vp, vp, sz, vp, sz, i, i, i, C.c_float, C.c_float],
+        "yakhip_truncate_depth": [vp, vp, sz, i, i, C.c_float],
+        "yakhip_depth_pyramid": [vp, vp, sz, i, i, vp, sz, C.c_float],
+        "yakhip_compute_points_normals": [vp, fp, vp, sz, i, i, vp, sz, vp, sz],
+        "yakhip_resize_points_normals": [vp, vp, sz, vp, sz, i, i, vp, sz, vp, sz],
+        "yakhip_icp_accumulate": [vp, fp, fp, fp, i, C.c_float, C.c_float, vp, sz, vp, sz, vp, sz, vp, sz, i, i, fp,
+                                  C.POINTER(i)],
     }
     for name, argtypes in sigs.items():
         fn = getattr(L, name)
@@ -175,6 +184,41 @@ class Context:
         _chk(load().yakhip_raycast_depth(self._h, C.byref(vol), _f32(R, 9), _f32(t, 3), _f32(Rinv, 9), _f32(intr, 4),
                                          step_factor, gradient_delta_factor, C.c_void_p(depth_ptr), depth_pitch,
                                          C.c_void_p(normals_ptr), normals_pitch, rows, cols))
+
+    # ---- tracking side ----
+    def bilateral_filter(self, src_ptr, src_pitch, dst_ptr, dst_pitch, rows, cols, kernel_size, sigma_spatial,
+                         sigma_depth):
+        _chk(load().yakhip_bilateral_filter(self._h, C.c_void_p(src_ptr), src_pitch, C.c_void_p(dst_ptr), dst_pitch,
+                                            rows, cols, kernel_size, sigma_spatial, sigma_depth))
+
+    def truncate_depth(self, depth_ptr, pitch, rows, cols, max_dist):
+        _chk(load().yakhip_truncate_depth(self._h, C.c_void_p(depth_ptr), pitch, rows, cols, max_dist))
+
+    def depth_pyramid(self, src_ptr, src_pitch, src_rows, src_cols, dst_ptr, dst_pitch, sigma_depth):
+        _chk(load().yakhip_depth_pyramid(self._h, C.c_void_p(src_ptr), src_pitch, src_rows, src_cols,
+                                         C.c_void_p(dst_ptr), dst_pitch, sigma_depth))
+
+    def compute_points_normals(self, intr, depth_ptr, depth_pitch, rows, cols, points_ptr, points_pitch, normals_ptr,
+                               normals_pitch):
+        _chk(load().yakhip_compute_points_normals(self._h, _f32(intr, 4), C.c_void_p(depth_ptr), depth_pitch, rows, cols,
+                                                  C.c_void_p(points_ptr), points_pitch, C.c_void_p(normals_ptr),
+                                                  normals_pitch))
+
+    def resize_points_normals(self, points_ptr, points_pitch, normals_ptr, normals_pitch, src_rows, src_cols,
+                              points_out_ptr, points_out_pitch, normals_out_ptr, normals_out_pitch):
+        _chk(load().yakhip_resize_points_normals(self._h, C.c_void_p(points_ptr), points_pitch, C.c_void_p(normals_ptr),
+                                                 normals_pitch, src_rows, src_cols, C.c_void_p(points_out_ptr),
+                                                 points_out_pitch, C.c_void_p(normals_out_ptr), normals_out_pitch))
+
+    def icp_accumulate(self, R, t, intr, level, dist_thres, angle_thres, vcurr_ptr, vcurr_pitch, ncurr_ptr, ncurr_pitch,
+                       vprev_ptr, vprev_pitch, nprev_ptr, nprev_pitch, rows, cols):
+        """Blocking.  Returns (sums: list of 27 floats, counts: list of 6 ints)."""
+        sums, counts = (C.c_float * 27)(), (C.c_int * 6)()
+        _chk(load().yakhip_icp_accumulate(self._h, _f32(R, 9), _f32(t, 3), _f32(intr, 4), int(level), dist_thres,
+                                          angle_thres, C.c_void_p(vcurr_ptr), vcurr_pitch, C.c_void_p(ncurr_ptr),
+                                          ncurr_pitch, C.c_void_p(vprev_ptr), vprev_pitch, C.c_void_p(nprev_ptr),
+                                          nprev_pitch, rows, cols, sums, counts))
+        return list(sums), list(counts)
 
 
 def volume_desc(data_ptr, dims, voxel_size, trunc_dist, max_weight, z0=0, z1=None):

@@ -124,6 +124,9 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->group_test = 1;
   ctx->thr = nullptr;
   ctx->thr_bytes = 0;
+  ctx->icp_scratch = nullptr;
+  ctx->icp_scratch_bytes = 0;
+  ctx->icp_pinned = nullptr;
   ctx->kernel_timing = 0;
   ctx->timing_used = 0;
   int rc = check(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
@@ -147,6 +150,10 @@ int yakhip_ctx_destroy(yakhip_ctx* ctx)
     rc = check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     if (ctx->thr)
       (void)hipFree(ctx->thr);
+    if (ctx->icp_scratch)
+      (void)hipFree(ctx->icp_scratch);
+    if (ctx->icp_pinned)
+      (void)hipHostFree(ctx->icp_pinned);
     for (auto& ev : ctx->timing_events)
     {
       (void)hipEventDestroy(ev.first);
@@ -517,6 +524,120 @@ int yakhip_raycast_depth(yakhip_ctx* ctx, const yakhip_volume* vol, const float 
     return fail(YAKHIP_EINVAL, "raycast(depth): null image pointer");
   return raycast_common(ctx, vol, R, t, Rinv, intr, step_factor, gradient_delta_factor, nullptr, 0, depth_dev,
                         depth_pitch, normals_dev, normals_pitch, rows, cols);
+}
+
+// ---- tracking side: depth pre-processing and ICP ----------------------------------------------
+
+int yakhip_bilateral_filter(yakhip_ctx* ctx, const void* src_dev, size_t src_pitch, void* dst_dev, size_t dst_pitch,
+                            int rows, int cols, int kernel_size, float sigma_spatial, float sigma_depth)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_image("bilateral(src)", src_dev, src_pitch, rows, cols, 2)) != 0)
+    return rc;
+  if ((rc = check_image("bilateral(dst)", dst_dev, dst_pitch, rows, cols, 2)) != 0)
+    return rc;
+  if (src_dev == dst_dev)
+    return fail(YAKHIP_EINVAL, "bilateral: in-place filtering is not supported");
+  if (kernel_size < 1 || kernel_size > 255 || !(sigma_spatial > 0.f) || !(sigma_depth > 0.f))
+    return fail(YAKHIP_EINVAL, "bilateral: kernel size must be in [1, 255] and both sigmas positive");
+  return launch_bilateral(ctx, (const uint8_t*)src_dev, src_pitch, (uint8_t*)dst_dev, dst_pitch, rows, cols,
+                          kernel_size, sigma_spatial, sigma_depth);
+}
+
+int yakhip_truncate_depth(yakhip_ctx* ctx, void* depth_dev, size_t depth_pitch, int rows, int cols, float max_dist)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_image("truncate_depth", depth_dev, depth_pitch, rows, cols, 2)) != 0)
+    return rc;
+  return launch_truncate_depth(ctx, (uint8_t*)depth_dev, depth_pitch, rows, cols, max_dist);
+}
+
+int yakhip_depth_pyramid(yakhip_ctx* ctx, const void* src_dev, size_t src_pitch, int src_rows, int src_cols,
+                         void* dst_dev, size_t dst_pitch, float sigma_depth)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_image("depth_pyramid(src)", src_dev, src_pitch, src_rows, src_cols, 2)) != 0)
+    return rc;
+  if (src_rows < 2 || src_cols < 2)
+    return fail(YAKHIP_EINVAL, "depth_pyramid: source must be at least 2 x 2");
+  if ((rc = check_image("depth_pyramid(dst)", dst_dev, dst_pitch, src_rows / 2, src_cols / 2, 2)) != 0)
+    return rc;
+  return launch_depth_pyramid(ctx, (const uint8_t*)src_dev, src_pitch, src_rows, src_cols, (uint8_t*)dst_dev,
+                              dst_pitch, sigma_depth);
+}
+
+int yakhip_compute_points_normals(yakhip_ctx* ctx, const float intr[4], const void* depth_dev, size_t depth_pitch,
+                                  int rows, int cols, void* points_dev, size_t points_pitch, void* normals_dev,
+                                  size_t normals_pitch)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!intr)
+    return fail(YAKHIP_EINVAL, "compute_points_normals: null intrinsics");
+  if ((rc = check_image("compute_points_normals(depth)", depth_dev, depth_pitch, rows, cols, 2)) != 0)
+    return rc;
+  if ((rc = check_image("compute_points_normals(points)", points_dev, points_pitch, rows, cols, 16)) != 0)
+    return rc;
+  if ((rc = check_image("compute_points_normals(normals)", normals_dev, normals_pitch, rows, cols, 16)) != 0)
+    return rc;
+  return launch_points_normals(ctx, intr, (const uint8_t*)depth_dev, depth_pitch, rows, cols, (uint8_t*)points_dev,
+                               points_pitch, (uint8_t*)normals_dev, normals_pitch);
+}
+
+int yakhip_resize_points_normals(yakhip_ctx* ctx, const void* points_dev, size_t points_pitch, const void* normals_dev,
+                                 size_t normals_pitch, int src_rows, int src_cols, void* points_out_dev,
+                                 size_t points_out_pitch, void* normals_out_dev, size_t normals_out_pitch)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_image("resize_points_normals(points)", points_dev, points_pitch, src_rows, src_cols, 16)) != 0)
+    return rc;
+  if ((rc = check_image("resize_points_normals(normals)", normals_dev, normals_pitch, src_rows, src_cols, 16)) != 0)
+    return rc;
+  if (src_rows < 2 || src_cols < 2)
+    return fail(YAKHIP_EINVAL, "resize_points_normals: source must be at least 2 x 2");
+  const int rows = src_rows / 2, cols = src_cols / 2;
+  if ((rc = check_image("resize_points_normals(points_out)", points_out_dev, points_out_pitch, rows, cols, 16)) != 0)
+    return rc;
+  if ((rc = check_image("resize_points_normals(normals_out)", normals_out_dev, normals_out_pitch, rows, cols, 16)) != 0)
+    return rc;
+  return launch_resize_points_normals(ctx, (const uint8_t*)points_dev, points_pitch, (const uint8_t*)normals_dev,
+                                      normals_pitch, src_rows, src_cols, (uint8_t*)points_out_dev, points_out_pitch,
+                                      (uint8_t*)normals_out_dev, normals_out_pitch);
+}
+
+int yakhip_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], int level,
+                          float dist_thres, float angle_thres, const void* vcurr_dev, size_t vcurr_pitch,
+                          const void* ncurr_dev, size_t ncurr_pitch, const void* vprev_dev, size_t vprev_pitch,
+                          const void* nprev_dev, size_t nprev_pitch, int rows, int cols, float sums_host[27],
+                          int counts_host[6])
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!R || !t || !intr || !sums_host)
+    return fail(YAKHIP_EINVAL, "icp_accumulate: null pose, intrinsics or output");
+  if (level < 0 || level > 15)
+    return fail(YAKHIP_EINVAL, "icp_accumulate: pyramid level %d outside [0, 15]", level);
+  if ((rc = check_image("icp_accumulate(vcurr)", vcurr_dev, vcurr_pitch, rows, cols, 16)) != 0)
+    return rc;
+  if ((rc = check_image("icp_accumulate(ncurr)", ncurr_dev, ncurr_pitch, rows, cols, 16)) != 0)
+    return rc;
+  if ((rc = check_image("icp_accumulate(vprev)", vprev_dev, vprev_pitch, rows, cols, 16)) != 0)
+    return rc;
+  if ((rc = check_image("icp_accumulate(nprev)", nprev_dev, nprev_pitch, rows, cols, 16)) != 0)
+    return rc;
+  return launch_icp_accumulate(ctx, R, t, intr, level, dist_thres, angle_thres, (const uint8_t*)vcurr_dev, vcurr_pitch,
+                               (const uint8_t*)ncurr_dev, ncurr_pitch, (const uint8_t*)vprev_dev, vprev_pitch,
+                               (const uint8_t*)nprev_dev, nprev_pitch, rows, cols, sums_host, counts_host);
 }
 
 }  // extern "C"

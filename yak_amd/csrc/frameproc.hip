@@ -1,0 +1,223 @@
+// frameproc.hip -- per-frame depth pre-processing for the tracking side of the KinFu loop, gfx950.
+// Replaces kfusion::device::{bilateralFilter, truncateDepth, depthPyr, computePointNormals,
+// resizePointsNormals} (yak/src/cuda/imgproc.cu:10-56, 66-85, 94-136, 210-250, 348-394).
+// Citations are relative to /root/reference/.
+//
+// These are small image-space kernels (640 x 480 and its pyramid): they are latency-, not
+// bandwidth-bound, so the only design rule is "wide rows, one pass": a wave covers 64 consecutive
+// pixels of a row, every tap goes through the vector L1, and every statement keeps the reference's
+// fp32 expression order (this TU is built with -ffp-contract=off).
+#include "yakhip_internal.h"
+
+namespace yakhip
+{
+namespace
+{
+__device__ __forceinline__ int u16_at(const uint8_t* base, uint32_t pitch, int y, int x)
+{
+  return ((const unsigned short*)(base + (size_t)y * pitch))[x];
+}
+
+// imgproc.cu:10-42
+__global__ __launch_bounds__(256) void bilateral_kernel(const uint8_t* src, uint32_t src_pitch, uint8_t* dst,
+                                                        uint32_t dst_pitch, int rows, int cols, int ksz,
+                                                        float sigma_spatial2_inv_half, float sigma_depth2_inv_half)
+{
+  const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+  const int y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+  if (x >= cols || y >= rows)
+    return;
+  const int value = u16_at(src, src_pitch, y, x);
+  const int tx = min(x - ksz / 2 + ksz, cols - 1);
+  const int ty = min(y - ksz / 2 + ksz, rows - 1);
+  float sum1 = 0.f, sum2 = 0.f;
+  for (int cy = max(y - ksz / 2, 0); cy < ty; ++cy)
+    for (int cx = max(x - ksz / 2, 0); cx < tx; ++cx)
+    {
+      const int depth = u16_at(src, src_pitch, cy, cx);
+      const float space2 = (float)((x - cx) * (x - cx) + (y - cy) * (y - cy));
+      const int dd = value - depth;
+      const float color2 = (float)(int)((unsigned)dd * (unsigned)dd);  // int product, wraps as the source's does
+      const float weight = expf(-(space2 * sigma_spatial2_inv_half + color2 * sigma_depth2_inv_half));
+      sum1 += (float)depth * weight;
+      sum2 += weight;
+    }
+  const float q = sum1 / sum2;
+  // __float2int_rn: round half even; NaN (an all-underflow window) -> 0
+  const int r = q != q ? 0 : (int)__builtin_rintf(q);
+  ((unsigned short*)(dst + (size_t)y * dst_pitch))[x] = (unsigned short)r;
+}
+
+// imgproc.cu:66-74
+__global__ __launch_bounds__(256) void truncate_depth_kernel(uint8_t* depth, uint32_t pitch, int rows, int cols,
+                                                             unsigned short max_dist)
+{
+  const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+  const int y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+  if (x >= cols || y >= rows)
+    return;
+  unsigned short* p = (unsigned short*)(depth + (size_t)y * pitch) + x;
+  if (*p > max_dist)
+    *p = 0;
+}
+
+// imgproc.cu:94-123
+__global__ __launch_bounds__(256) void pyramid_kernel(const uint8_t* src, uint32_t src_pitch, int src_rows, int src_cols,
+                                                      uint8_t* dst, uint32_t dst_pitch, int rows, int cols,
+                                                      float sigma_depth_mult3)
+{
+  const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+  const int y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+  if (x >= cols || y >= rows)
+    return;
+  const int D = 5;
+  const int center = u16_at(src, src_pitch, 2 * y, 2 * x);
+  const int tx = min(2 * x - D / 2 + D, src_cols - 1);
+  const int ty = min(2 * y - D / 2 + D, src_rows - 1);
+  int sum = 0, count = 0;
+  for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+    for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx)
+    {
+      const int val = u16_at(src, src_pitch, cy, cx);
+      if ((float)abs(val - center) < sigma_depth_mult3)
+      {
+        sum += val;
+        ++count;
+      }
+    }
+  ((unsigned short*)(dst + (size_t)y * dst_pitch))[x] = (unsigned short)(count == 0 ? 0 : sum / count);
+}
+
+// device.hpp:57-62
+__device__ __forceinline__ void reproj(float finvx, float finvy, float cx, float cy, int u, int v, float z, float& ox,
+                                       float& oy)
+{
+  ox = z * ((float)u - cx) * finvx;
+  oy = z * ((float)v - cy) * finvy;
+}
+
+// imgproc.cu:210-239
+__global__ __launch_bounds__(256) void points_normals_kernel(float finvx, float finvy, float cx, float cy,
+                                                             const uint8_t* depth, uint32_t depth_pitch, int rows,
+                                                             int cols, uint8_t* points, uint32_t points_pitch,
+                                                             uint8_t* normals, uint32_t normals_pitch)
+{
+  const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+  const int y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+  if (x >= cols || y >= rows)
+    return;
+  const float qnan = __builtin_nanf("");
+  float4 p = make_float4(qnan, qnan, qnan, qnan), n = p;
+  if (x < cols - 1 && y < rows - 1)
+  {
+    const float z00 = (float)u16_at(depth, depth_pitch, y, x) * 0.001f;
+    const float z01 = (float)u16_at(depth, depth_pitch, y, x + 1) * 0.001f;
+    const float z10 = (float)u16_at(depth, depth_pitch, y + 1, x) * 0.001f;
+    if (z00 * z01 * z10 != 0.f)
+    {
+      float v00x, v00y, v01x, v01y, v10x, v10y;
+      reproj(finvx, finvy, cx, cy, x, y, z00, v00x, v00y);
+      reproj(finvx, finvy, cx, cy, x + 1, y, z01, v01x, v01y);
+      reproj(finvx, finvy, cx, cy, x, y + 1, z10, v10x, v10y);
+      const float ax = v01x - v00x, ay = v01y - v00y, az = z01 - z00;
+      const float bx = v10x - v00x, by = v10y - v00y, bz = z10 - z00;
+      const float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;  // temp_utils.hpp:105-108
+      const float s = 1.0f / __builtin_sqrtf(dot3(nx, ny, nz, nx, ny, nz));             // normalized, :103
+      n = make_float4(-(nx * s), -(ny * s), -(nz * s), 0.f);
+      p = make_float4(v00x, v00y, z00, 0.f);
+    }
+  }
+  ((float4*)(points + (size_t)y * points_pitch))[x] = p;
+  ((float4*)(normals + (size_t)y * normals_pitch))[x] = n;
+}
+
+__device__ __forceinline__ float4 f4_at(const uint8_t* base, uint32_t pitch, int y, int x)
+{
+  return ((const float4*)(base + (size_t)y * pitch))[x];
+}
+
+// imgproc.cu:348-380
+__global__ __launch_bounds__(256) void resize_points_normals_kernel(const uint8_t* vsrc, uint32_t vsrc_pitch,
+                                                                    const uint8_t* nsrc, uint32_t nsrc_pitch,
+                                                                    uint8_t* vdst, uint32_t vdst_pitch, uint8_t* ndst,
+                                                                    uint32_t ndst_pitch, int rows, int cols)
+{
+  const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+  const int y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+  if (x >= cols || y >= rows)
+    return;
+  const float qnan = __builtin_nanf("");
+  float4 v = make_float4(qnan, qnan, qnan, 0.f), n = v;
+  const int xs = 2 * x, ys = 2 * y;
+  const float4 d00 = f4_at(vsrc, vsrc_pitch, ys + 0, xs + 0);
+  const float4 d01 = f4_at(vsrc, vsrc_pitch, ys + 0, xs + 1);
+  const float4 d10 = f4_at(vsrc, vsrc_pitch, ys + 1, xs + 0);
+  const float4 d11 = f4_at(vsrc, vsrc_pitch, ys + 1, xs + 1);
+  const float prod = d00.x * d01.x * d10.x * d11.x;
+  if (!(prod != prod))
+  {
+    v = make_float4((d00.x + d01.x + d10.x + d11.x) * 0.25f, (d00.y + d01.y + d10.y + d11.y) * 0.25f,
+                    (d00.z + d01.z + d10.z + d11.z) * 0.25f, 0.f);
+    const float4 n00 = f4_at(nsrc, nsrc_pitch, ys + 0, xs + 0);
+    const float4 n01 = f4_at(nsrc, nsrc_pitch, ys + 0, xs + 1);
+    const float4 n10 = f4_at(nsrc, nsrc_pitch, ys + 1, xs + 0);
+    const float4 n11 = f4_at(nsrc, nsrc_pitch, ys + 1, xs + 1);
+    n = make_float4((n00.x + n01.x + n10.x + n11.x) * 0.25f, (n00.y + n01.y + n10.y + n11.y) * 0.25f,
+                    (n00.z + n01.z + n10.z + n11.z) * 0.25f, 0.f);
+  }
+  ((float4*)(vdst + (size_t)y * vdst_pitch))[x] = v;
+  ((float4*)(ndst + (size_t)y * ndst_pitch))[x] = n;
+}
+
+inline dim3 image_grid(int rows, int cols) { return dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 3) / 4)); }
+}  // namespace
+
+int launch_bilateral(const yakhip_ctx* ctx, const uint8_t* src, size_t src_pitch, uint8_t* dst, size_t dst_pitch,
+                     int rows, int cols, int kernel_size, float sigma_spatial, float sigma_depth)
+{
+  sigma_depth *= 1000;  // imgproc.cu:48 metres -> mm
+  hipLaunchKernelGGL(bilateral_kernel, image_grid(rows, cols), dim3(256), 0, ctx->stream, src, (uint32_t)src_pitch, dst,
+                     (uint32_t)dst_pitch, rows, cols, kernel_size, 0.5f / (sigma_spatial * sigma_spatial),
+                     0.5f / (sigma_depth * sigma_depth));  // :54
+  return check(hipGetLastError(), "bilateral_kernel launch");
+}
+
+int launch_truncate_depth(const yakhip_ctx* ctx, uint8_t* depth, size_t pitch, int rows, int cols, float max_dist)
+{
+  const float mm = max_dist * 1000.f;  // imgproc.cu:83, saturating truncation as the GPU conversion does
+  const unsigned short lim = (unsigned short)(mm >= 65535.f ? 65535 : (mm > 0.f ? (int)mm : 0));
+  hipLaunchKernelGGL(truncate_depth_kernel, image_grid(rows, cols), dim3(256), 0, ctx->stream, depth, (uint32_t)pitch,
+                     rows, cols, lim);
+  return check(hipGetLastError(), "truncate_depth_kernel launch");
+}
+
+int launch_depth_pyramid(const yakhip_ctx* ctx, const uint8_t* src, size_t src_pitch, int src_rows, int src_cols,
+                         uint8_t* dst, size_t dst_pitch, float sigma_depth)
+{
+  const int rows = src_rows / 2, cols = src_cols / 2;  // imgproc.cpp:17
+  hipLaunchKernelGGL(pyramid_kernel, image_grid(rows, cols), dim3(256), 0, ctx->stream, src, (uint32_t)src_pitch,
+                     src_rows, src_cols, dst, (uint32_t)dst_pitch, rows, cols, sigma_depth * 1000 * 3);  // :129,:134
+  return check(hipGetLastError(), "pyramid_kernel launch");
+}
+
+int launch_points_normals(const yakhip_ctx* ctx, const float intr[4], const uint8_t* depth, size_t depth_pitch, int rows,
+                          int cols, uint8_t* points, size_t points_pitch, uint8_t* normals, size_t normals_pitch)
+{
+  hipLaunchKernelGGL(points_normals_kernel, image_grid(rows, cols), dim3(256), 0, ctx->stream, 1.f / intr[0],
+                     1.f / intr[1], intr[2], intr[3], depth, (uint32_t)depth_pitch, rows, cols, points,
+                     (uint32_t)points_pitch, normals, (uint32_t)normals_pitch);
+  return check(hipGetLastError(), "points_normals_kernel launch");
+}
+
+int launch_resize_points_normals(const yakhip_ctx* ctx, const uint8_t* points, size_t points_pitch,
+                                 const uint8_t* normals, size_t normals_pitch, int src_rows, int src_cols,
+                                 uint8_t* points_out, size_t points_out_pitch, uint8_t* normals_out,
+                                 size_t normals_out_pitch)
+{
+  const int rows = src_rows / 2, cols = src_cols / 2;  // imgproc.cu:386-387
+  hipLaunchKernelGGL(resize_points_normals_kernel, image_grid(rows, cols), dim3(256), 0, ctx->stream, points,
+                     (uint32_t)points_pitch, normals, (uint32_t)normals_pitch, points_out, (uint32_t)points_out_pitch,
+                     normals_out, (uint32_t)normals_out_pitch, rows, cols);
+  return check(hipGetLastError(), "resize_points_normals_kernel launch");
+}
+}  // namespace yakhip

@@ -21,6 +21,9 @@ struct yakhip_ctx
   int group_test;      // coarse group test on (default) / off
   void* thr;           // scratch: per-pixel band thresholds of the frame being integrated
   size_t thr_bytes;
+  void* icp_scratch;   // ICP: workgroup partials + the reduced 33 values (device)
+  size_t icp_scratch_bytes;
+  void* icp_pinned;    // ICP: pinned host mirror of the 33 values
   int kernel_timing;   // record a hipEvent pair around every integrate_kernel launch
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_events;
   size_t timing_used;
@@ -99,6 +102,24 @@ int launch_clear(const yakhip_ctx* ctx, uint32_t* data, size_t n_voxels);
 int launch_selftest_division(yakhip_ctx* ctx, unsigned long long counts[4]);
 int launch_compute_dists(const yakhip_ctx* ctx, const uint8_t* depth, size_t depth_pitch, uint8_t* dists,
                          size_t dists_pitch, int rows, int cols, float fx, float fy, float cx, float cy);
+
+// frameproc.hip
+int launch_bilateral(const yakhip_ctx* ctx, const uint8_t* src, size_t src_pitch, uint8_t* dst, size_t dst_pitch,
+                     int rows, int cols, int kernel_size, float sigma_spatial, float sigma_depth);
+int launch_truncate_depth(const yakhip_ctx* ctx, uint8_t* depth, size_t pitch, int rows, int cols, float max_dist);
+int launch_depth_pyramid(const yakhip_ctx* ctx, const uint8_t* src, size_t src_pitch, int src_rows, int src_cols,
+                         uint8_t* dst, size_t dst_pitch, float sigma_depth);
+int launch_points_normals(const yakhip_ctx* ctx, const float intr[4], const uint8_t* depth, size_t depth_pitch, int rows,
+                          int cols, uint8_t* points, size_t points_pitch, uint8_t* normals, size_t normals_pitch);
+int launch_resize_points_normals(const yakhip_ctx* ctx, const uint8_t* points, size_t points_pitch,
+                                 const uint8_t* normals, size_t normals_pitch, int src_rows, int src_cols,
+                                 uint8_t* points_out, size_t points_out_pitch, uint8_t* normals_out,
+                                 size_t normals_out_pitch);
+// icp.hip (blocking: returns after the 27 sums and 6 counters are on the host)
+int launch_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], int level,
+                          float dist_thres, float angle_thres, const uint8_t* vcurr, size_t vcurr_pitch,
+                          const uint8_t* ncurr, size_t ncurr_pitch, const uint8_t* vprev, size_t vprev_pitch,
+                          const uint8_t* nprev, size_t nprev_pitch, int rows, int cols, float sums[27], int counts[6]);
 
 // ---- device helpers shared by kernels --------------------------------------------------------
 __device__ __forceinline__ float half_bits_to_float(uint32_t bits)
