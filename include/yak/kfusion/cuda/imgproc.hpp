@@ -9,6 +9,16 @@ namespace cuda
 {
 /** depth (mm) -> ray length (m, half): reference imgproc.cpp:45-49, imgproc.cu:259-283. */
 KF_EXPORTS void computeDists(const Depth& depth, Dists& dists, const Intr& intr);
+/** Edge-preserving smoothing of the depth frame (reference imgproc.cpp:3-11, imgproc.cu:10-56). */
+KF_EXPORTS void depthBilateralFilter(const Depth& in, Depth& out, int ksz, float sigma_spatial, float sigma_depth);
+/** depth > threshold (metres) -> 0, in place (reference imgproc.cpp:13, imgproc.cu:66-85). */
+KF_EXPORTS void depthTruncation(Depth& depth, float threshold);
+/** Half-resolution level of the depth pyramid (reference imgproc.cpp:15-19, imgproc.cu:94-136). */
+KF_EXPORTS void depthBuildPyramid(const Depth& depth, Depth& pyramid, float sigma_depth);
+/** Back-projection + triangle normals (reference imgproc.cpp:33-43, imgproc.cu:210-250). */
+KF_EXPORTS void computePointNormals(const Intr& intr, const Depth& depth, Cloud& points, Normals& normals);
+/** 2 x 2 box average of point / normal maps (reference imgproc.cpp:65-80, imgproc.cu:348-394). */
+KF_EXPORTS void resizePointsNormals(const Cloud& points, const Normals& normals, Cloud& points_out, Normals& normals_out);
 /** Blocks until everything queued so far is done (reference imgproc.cpp:21: cudaDeviceSynchronize). */
 KF_EXPORTS void waitAllDefaultStream();
 }  // namespace cuda

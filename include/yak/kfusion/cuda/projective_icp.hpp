@@ -30,10 +30,13 @@ public:
   void setIterationsNum(const std::vector<int>& iters);
   int getUsedLevelsNum() const;
 
-  /** Points variant (reference projective_icp.cpp:175-232).  Not available yet in this build:
-   *  throws std::logic_error. */
-  virtual bool estimateTransform(Affine3f& affine, Affine3f& corrected, const Intr& intr, const PointsPyr& vcurr,
-                                 const NormalsPyr ncurr, const PointsPyr vprev, const NormalsPyr nprev);
+  /** Points variant (reference projective_icp.cpp:175-232): refines `affine` (current -> previous
+   *  camera) coarse to fine against the previous frame's maps; false when the normal matrix is
+   *  (numerically) singular.  The Depth variant belongs to the reference's disabled USE_DEPTH build
+   *  (internal.hpp:8) and the Frame overload is a CV_Assert(!"Not implemented") there (:106-123). */
+  virtual bool estimateTransform(const Affine3f& affine, Affine3f& correctedAffine, const Intr& intr,
+                                 const PointsPyr& vcurr, const NormalsPyr ncurr, const PointsPyr vprev,
+                                 const NormalsPyr nprev);
 
 private:
   std::vector<int> iters_;

@@ -5,6 +5,8 @@
 
 #include <yak_oracle.h>
 
+#include "../../yak_amd/host/solve6.hpp"
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -97,6 +99,63 @@ static void test_container_and_half()  // reference test/marching_cubes_tests.cp
   }
   kfusion::cuda::ProjectiveICP icp;  // levels with a non-zero iteration count: {10,5,4,0} -> 3
   EXPECT(icp.getUsedLevelsNum() == 3);
+}
+
+static void test_solve6()  // stands in for cv::determinant / cv::solve(DECOMP_SVD), projective_icp.cpp:215,225
+{
+  std::printf("solve6: determinant and SVD solve of the 6 x 6 normal equations\n");
+  // A = M^T M + I for a fixed M: symmetric positive definite
+  double M[36], A[36], xs[6], b[6], x[6];
+  for (int i = 0; i < 36; ++i)
+    M[i] = std::sin(1.0 + 0.7 * i) + (i % 7 == 0 ? 2.0 : 0.0);
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c)
+    {
+      double s = r == c ? 1.0 : 0.0;
+      for (int k = 0; k < 6; ++k)
+        s += M[k * 6 + r] * M[k * 6 + c];
+      A[r * 6 + c] = s;
+    }
+  for (int i = 0; i < 6; ++i)
+    xs[i] = 0.25 * (i - 2.5);
+  for (int r = 0; r < 6; ++r)
+  {
+    b[r] = 0;
+    for (int c = 0; c < 6; ++c)
+      b[r] += A[r * 6 + c] * xs[c];
+  }
+  yak::host::solve6_svd_symmetric(A, b, x);
+  for (int i = 0; i < 6; ++i)
+    EXPECT(std::fabs(x[i] - xs[i]) < 1e-10);
+  // determinant: diagonal, a row swap, and det(A) = prod(eigenvalues) > 0 for the SPD matrix
+  double D[36] = { 0 };
+  for (int i = 0; i < 6; ++i)
+    D[i * 7] = i + 1.0;
+  EXPECT(std::fabs(yak::host::det6(D) - 720.0) < 1e-9);
+  for (int c = 0; c < 6; ++c)
+  {
+    const double t = D[c];
+    D[c] = D[6 + c];
+    D[6 + c] = t;
+  }
+  EXPECT(std::fabs(yak::host::det6(D) + 720.0) < 1e-9);
+  EXPECT(yak::host::det6(A) > 1.0);
+  // rank-deficient system: the SVD solve returns the minimum-norm solution (no component along the null vector)
+  double P[36] = { 0 }, rhs[6] = { 1, 2, 3, 4, 5, 0 };
+  for (int i = 0; i < 5; ++i)
+    P[i * 7] = 2.0;  // last row / column zero
+  yak::host::solve6_svd_symmetric(P, rhs, x);
+  for (int i = 0; i < 5; ++i)
+    EXPECT(std::fabs(x[i] - rhs[i] / 2.0) < 1e-12);
+  EXPECT(x[5] == 0.0 && yak::host::det6(P) == 0.0);
+
+  kfusion::cuda::ProjectiveICP icp;  // projective_icp.cpp:87-104
+  icp.setIterationsNum(std::vector<int>{ 3, 2 });
+  EXPECT(icp.getUsedLevelsNum() == 2);
+  icp.setIterationsNum(std::vector<int>{ 1, 0, 0, 7, 9, 9 });  // cut to MAX_PYRAMID_LEVELS
+  EXPECT(icp.getUsedLevelsNum() == 4);
+  icp.setIterationsNum(std::vector<int>{});
+  EXPECT(icp.getUsedLevelsNum() == 0);
 }
 
 static void test_no_gpu_is_an_exception()
@@ -224,6 +283,121 @@ static void test_fusion_server_against_oracle()
   EXPECT(nz == 0);
 }
 
+// camera -> volume pose looking from `eye` at `target`, +y down (the convention of the depth frames)
+static Affine3f look_at(const double eye[3], const double target[3])
+{
+  double f[3] = { target[0] - eye[0], target[1] - eye[1], target[2] - eye[2] };
+  const double fn = std::sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+  for (double& v : f)
+    v /= fn;
+  const double down0[3] = { 0, 1, 0 };
+  double r[3] = { down0[1] * f[2] - down0[2] * f[1], down0[2] * f[0] - down0[0] * f[2], down0[0] * f[1] - down0[1] * f[0] };
+  const double rn = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  for (double& v : r)
+    v /= rn;
+  const double d[3] = { f[1] * r[2] - f[2] * r[1], f[2] * r[0] - f[0] * r[2], f[0] * r[1] - f[1] * r[0] };
+  kfusion::Mat3f R;
+  for (int i = 0; i < 3; ++i)
+  {
+    R(i, 0) = (float)r[i];
+    R(i, 1) = (float)d[i];
+    R(i, 2) = (float)f[i];
+  }
+  return Affine3f(R, Vec3f((float)eye[0], (float)eye[1], (float)eye[2]));
+}
+
+// ground plane y = 1.95 and three spheres (SURVEY.md 8d scene S2: a lone sphere leaves ICP rank-deficient)
+static std::vector<std::uint16_t> render_s2(const Affine3f& cam, const kfusion::Intr& in, int rows, int cols)
+{
+  static const double sph[3][4] = { { 1.1, 1.45, 1.2, 0.5 }, { 2.0, 1.6, 1.4, 0.35 }, { 1.5, 1.7, 2.1, 0.25 } };
+  std::vector<std::uint16_t> depth((size_t)rows * cols, 0);
+  const kfusion::Mat3f R = cam.rotation();
+  const Vec3f o = cam.translation();
+  for (int v = 0; v < rows; ++v)
+    for (int u = 0; u < cols; ++u)
+    {
+      const double dc[3] = { (u - in.cx) / in.fx, (v - in.cy) / in.fy, 1.0 };
+      double d[3];
+      for (int i = 0; i < 3; ++i)
+        d[i] = R(i, 0) * dc[0] + R(i, 1) * dc[1] + R(i, 2) * dc[2];
+      double best = 1e30;
+      if (std::fabs(d[1]) > 1e-12)
+      {
+        const double s = (1.95 - o[1]) / d[1];
+        if (s > 1e-6)
+          best = s;
+      }
+      for (const auto& sp : sph)
+      {
+        const double oc[3] = { o[0] - sp[0], o[1] - sp[1], o[2] - sp[2] };
+        const double a = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], b = 2 * (d[0] * oc[0] + d[1] * oc[1] + d[2] * oc[2]),
+                     c = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2] - sp[3] * sp[3], disc = b * b - 4 * a * c;
+        if (disc >= 0)
+        {
+          const double s = (-b - std::sqrt(disc)) / (2 * a);
+          if (s > 1e-6 && s < best)
+            best = s;
+        }
+      }
+      const double mm = std::floor(best * 1000.0 + 0.5);
+      depth[(size_t)v * cols + u] = (best < 1e29 && mm > 0 && mm < 65535) ? (std::uint16_t)mm : 0;
+    }
+  return depth;
+}
+
+static Affine3f orbit_pose(int frame)
+{
+  const double ang = 1.2 * frame * 3.14159265358979323846 / 180.0, centre[3] = { 1.5, 1.5, 1.5 };
+  const double eye[3] = { 1.5 + 3.2 * std::sin(ang), 1.5, 1.5 - 3.2 * std::cos(ang) };
+  return look_at(eye, centre);
+}
+
+// The complete KinFu loop (kinfu.cpp:162-309) with ICP on: bilateral / pyramid / point maps, ICP against
+// the ray-cast model, integrate, ray-cast.  No pose is supplied after frame 0: the tracked poses must
+// follow the true orbit.
+static void test_kinfu_icp_tracks_orbit()
+{
+  std::printf("KinFu with use_icp: tracks the S2 orbit from depth alone\n");
+  kfusion::KinFuParams p = kfusion::KinFuParams::default_params();
+  p.volume_dims = kfusion::Vec3i::all(128);
+  p.volume_resolution = 3.f / 128.f;
+  p.volume_pose = orbit_pose(0);  // frame 0 is integrated at this pose (kinfu.cpp:193)
+  kfusion::KinFu kinfu(p);
+  const int frames = 12;
+  double worst_t = 0, worst_r = 0;
+  for (int f = 0; f < frames; ++f)
+  {
+    const Affine3f truth = orbit_pose(f);
+    std::vector<std::uint16_t> depth = render_s2(truth, p.intr, p.rows, p.cols);
+    kfusion::cuda::Depth d;
+    d.upload(depth.data(), (size_t)p.cols * 2, p.rows, p.cols);
+    // the supplied poses are ignored when use_icp && update_via_sensor_motion (kinfu.cpp:229-262)
+    const bool ok = kinfu(Affine3f::Identity(), Affine3f::Identity(), Affine3f::Identity(), d);
+    EXPECT(ok == (f > 0));
+    const Affine3f est = kinfu.getCameraPose();
+    const Affine3f err = truth.inv() * est;
+    const double terr = yak::compat::norm(err.translation()), rerr = yak::compat::norm(err.rvec()) * 180.0 / 3.14159265;
+    if (terr > worst_t)
+      worst_t = terr;
+    if (rerr > worst_r)
+      worst_r = rerr;
+  }
+  std::printf("  %d frames, worst pose error: %.2f mm, %.3f deg (voxel %.1f mm, step 1.2 deg = 67 mm)\n", frames,
+              worst_t * 1e3, worst_r, 3000.0 / 128);
+  // drift bound: half a voxel and half a degree over the run (a lost track is off by the 67 mm / 1.2 deg steps)
+  EXPECT(worst_t < 0.5 * 3.0 / 128 && worst_r < 0.5);
+
+  // a featureless frame makes the normal matrix singular: the loop reports failure and starts over
+  // (kinfu.cpp:247-252)
+  std::vector<std::uint16_t> blank((size_t)p.rows * p.cols, 0);
+  kfusion::cuda::Depth d;
+  d.upload(blank.data(), (size_t)p.cols * 2, p.rows, p.cols);
+  EXPECT(!kinfu(Affine3f::Identity(), Affine3f::Identity(), Affine3f::Identity(), d));
+  const Affine3f after = kinfu.getCameraPose();
+  for (int i = 0; i < 16; ++i)
+    EXPECT(after.matrix.val[i] == p.volume_pose.matrix.val[i]);
+}
+
 static void test_device_arrays()
 {
   std::printf("DeviceArray / DeviceArray2D\n");
@@ -255,6 +429,7 @@ int main(int argc, char** argv)
       test_params_defaults();
       test_affine_math();
       test_container_and_half();
+      test_solve6();
       test_no_gpu_is_an_exception();
     }
     else
@@ -262,6 +437,7 @@ int main(int argc, char** argv)
       std::printf("device: %s\n", kfusion::cuda::getDeviceName(0).c_str());
       test_device_arrays();
       test_fusion_server_against_oracle();
+      test_kinfu_icp_tracks_orbit();
     }
   }
   catch (const std::exception& e)

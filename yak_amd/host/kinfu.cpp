@@ -1,5 +1,4 @@
-// kfusion::KinFu -- the per-frame loop (reference yak/src/kfusion/kinfu.cpp:10-309) and
-// ProjectiveICP's parameter front (reference yak/src/kfusion/projective_icp.cpp:66-104).
+// kfusion::KinFu -- the per-frame loop (reference yak/src/kfusion/kinfu.cpp:10-309).
 #include <yak/kfusion/cuda/imgproc.hpp>
 #include <yak/kfusion/kinfu.hpp>
 
@@ -38,41 +37,6 @@ KinFuParams KinFuParams::default_params()
   return p;
 }
 
-namespace cuda
-{
-// projective_icp.cpp:66-104
-ProjectiveICP::ProjectiveICP() : angle_thres_(deg2rad(20.f)), dist_thres_(0.1f)
-{
-  const int iters[] = { 10, 5, 4, 0 };
-  iters_.assign(iters, iters + 4);
-}
-ProjectiveICP::~ProjectiveICP() {}
-float ProjectiveICP::getDistThreshold() const { return dist_thres_; }
-void ProjectiveICP::setDistThreshold(float distance) { dist_thres_ = distance; }
-float ProjectiveICP::getAngleThreshold() const { return angle_thres_; }
-void ProjectiveICP::setAngleThreshold(float angle) { angle_thres_ = angle; }
-void ProjectiveICP::setIterationsNum(const std::vector<int>& iters)
-{
-  if (iters.size() > MAX_PYRAMID_LEVELS)
-    throw std::invalid_argument("ProjectiveICP: at most MAX_PYRAMID_LEVELS iteration counts");
-  iters_ = iters;
-}
-int ProjectiveICP::getUsedLevelsNum() const  // number of leading levels with a non-zero count
-{
-  int i = MAX_PYRAMID_LEVELS - 1;
-  for (; i >= 0; --i)
-    if (i < (int)iters_.size() && iters_[i] > 0)
-      break;
-  return i + 1;
-}
-bool ProjectiveICP::estimateTransform(Affine3f&, Affine3f&, const Intr&, const PointsPyr&, const NormalsPyr,
-                                      const PointsPyr, const NormalsPyr)
-{
-  throw std::logic_error("ProjectiveICP::estimateTransform: ICP kernels are not built yet (SURVEY section 8f rank 2); "
-                         "run with KinFuParams::use_icp = false (pose hints)");
-}
-}  // namespace cuda
-
 // kinfu.cpp:50-80
 KinFu::KinFu(const KinFuParams& params) : frame_counter_(0), params_(params)
 {
@@ -105,7 +69,30 @@ cuda::TsdfVolume& KinFu::tsdf() { return *volume_; }
 const cuda::ProjectiveICP& KinFu::icp() const { return *icp_; }
 cuda::ProjectiveICP& KinFu::icp() { return *icp_; }
 
-void KinFu::allocate_buffers() { dists_.create(params_.rows, params_.cols); }  // kinfu.cpp:94-129 (fusion part)
+void KinFu::allocate_buffers()  // kinfu.cpp:94-129 (the USE_DEPTH-only depth pyramid of prev_ is not kept)
+{
+  const int LEVELS = cuda::ProjectiveICP::MAX_PYRAMID_LEVELS;
+  int cols = params_.cols, rows = params_.rows;
+  dists_.create(rows, cols);
+  curr_.depth_pyr.resize(LEVELS);
+  curr_.normals_pyr.resize(LEVELS);
+  curr_.points_pyr.resize(LEVELS);
+  prev_.normals_pyr.resize(LEVELS);
+  prev_.points_pyr.resize(LEVELS);
+  for (int i = 0; i < LEVELS; ++i)
+  {
+    curr_.depth_pyr[i].create(rows, cols);
+    curr_.normals_pyr[i].create(rows, cols);
+    curr_.points_pyr[i].create(rows, cols);
+    prev_.normals_pyr[i].create(rows, cols);
+    prev_.points_pyr[i].create(rows, cols);
+    cols /= 2;
+    rows /= 2;
+  }
+  depths_.create(params_.rows, params_.cols);
+  normals_.create(params_.rows, params_.cols);
+  points_.create(params_.rows, params_.cols);
+}
 
 void KinFu::resetPose()  // kinfu.cpp:131-146
 {
@@ -130,13 +117,26 @@ bool KinFu::operator()(const Affine3f& inputCameraMotion, const Affine3f& curren
                        const Affine3f& previousCameraPose, const cuda::Depth& depth, const cuda::Image& /*image*/)
 {
   const KinFuParams& p = params_;
+  const int LEVELS = icp_->getUsedLevelsNum();
+
   cuda::computeDists(depth, dists_, p.intr);  // :171
-  // :172-186 (bilateral filter, pyramid, point normals) only feed ICP; they come with it
+  // :172-186 feed ICP only; the reference runs them on every frame regardless of use_icp, and so
+  // does this loop (prev_ must hold frame 0's maps when tracking starts on frame 1)
+  cuda::depthBilateralFilter(depth, curr_.depth_pyr[0], p.bilateral_kernel_size, p.bilateral_sigma_spatial,
+                             p.bilateral_sigma_depth);
+  if (p.icp_truncate_depth_dist > 0)
+    cuda::depthTruncation(curr_.depth_pyr[0], p.icp_truncate_depth_dist);
+  for (int i = 1; i < LEVELS; ++i)
+    cuda::depthBuildPyramid(curr_.depth_pyr[i - 1], curr_.depth_pyr[i], p.bilateral_sigma_depth);
+  for (int i = 0; i < LEVELS; ++i)
+    cuda::computePointNormals(p.intr(i), curr_.depth_pyr[i], curr_.points_pyr[i], curr_.normals_pyr[i]);
   cuda::waitAllDefaultStream();  // :188
 
   if (frame_counter_ == 0)  // :191-201 -- integrates at the stored pose, reports false
   {
     volume_->integrate(dists_, poses_.back(), p.intr);
+    curr_.points_pyr.swap(prev_.points_pyr);
+    curr_.normals_pyr.swap(prev_.normals_pyr);
     return ++frame_counter_, false;
   }
 
@@ -176,7 +176,12 @@ bool KinFu::operator()(const Affine3f& inputCameraMotion, const Affine3f& curren
   if ((rnorm + tnorm) / 2 >= p.tsdf_min_camera_movement)
     volume_->integrate(dists_, poses_.back(), p.intr);
 
-  // :294-306 (raycast of the model for the next frame's ICP) comes with the raycast kernel
+  // :294-306 -- the model as seen from the new pose becomes the next frame's ICP target
+  volume_->raycast(poses_.back(), p.intr, prev_.points_pyr[0], prev_.normals_pyr[0]);
+  for (int i = 1; i < LEVELS; ++i)
+    cuda::resizePointsNormals(prev_.points_pyr[i - 1], prev_.normals_pyr[i - 1], prev_.points_pyr[i],
+                              prev_.normals_pyr[i]);
+  cuda::waitAllDefaultStream();
   return ++frame_counter_, true;
 }
 }  // namespace kfusion

@@ -1,5 +1,5 @@
 // kfusion::cuda::TsdfVolume host side (reference yak/src/kfusion/tsdf_volume.cpp:19-145) and the
-// imgproc wrappers this path needs (reference yak/src/kfusion/imgproc.cpp:21,45-49).
+// imgproc wrappers (reference yak/src/kfusion/imgproc.cpp:3-80).
 #include <yak/kfusion/cuda/imgproc.hpp>
 #include <yak/kfusion/cuda/tsdf_volume.hpp>
 
@@ -192,13 +192,49 @@ void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_motion_tfo
   YAK_CHECK(yakhip_ctx_synchronize(context()));
 }
 
-void TsdfVolume::raycast(const Affine3f&, const Intr&, Depth&, Normals&)
+namespace
 {
-  throw std::logic_error("TsdfVolume::raycast(depth): not built yet (SURVEY section 8f rank 1)");
+// :114-119 / :133-138: cam2vol = pose_^-1 * camera_pose, Rinv = its rotation inverted (DECOMP_SVD in
+// the reference; Matx33f::inv here -- the same matrix up to rounding, parity unpinned: DESIGN.md)
+struct RaycastPose
+{
+  float R[9], t[3], Rinv[9];
+};
+RaycastPose raycast_pose(const Affine3f& pose, const Affine3f& camera_pose)
+{
+  const Affine3f cam2vol = pose.inv() * camera_pose;
+  const Mat3f R = cam2vol.rotation(), Rinv = cam2vol.rotation().inv(cv::DECOMP_SVD);
+  const Vec3f t = cam2vol.translation();
+  RaycastPose o;
+  for (int i = 0; i < 9; ++i)
+  {
+    o.R[i] = R.val[i];
+    o.Rinv[i] = Rinv.val[i];
+  }
+  for (int i = 0; i < 3; ++i)
+    o.t[i] = t[i];
+  return o;
 }
-void TsdfVolume::raycast(const Affine3f&, const Intr&, Cloud&, Normals&)
+}  // namespace
+
+// :110-126
+void TsdfVolume::raycast(const Affine3f& camera_pose, const Intr& intr, Depth& depth, Normals& normals)
 {
-  throw std::logic_error("TsdfVolume::raycast(points): not built yet (SURVEY section 8f rank 1)");
+  const RaycastPose rp = raycast_pose(pose_, camera_pose);
+  const float in[4] = { intr.fx, intr.fy, intr.cx, intr.cy };
+  yakhip_volume v = make_view(data_.ptr<void>(), dims_, getVoxelSize(), trunc_dist_, max_weight_);
+  YAK_CHECK(yakhip_raycast_depth(context(), &v, rp.R, rp.t, rp.Rinv, in, raycast_step_factor_, gradient_delta_factor_,
+                                 depth.ptr(), depth.step(), normals.ptr(), normals.step(), depth.rows(), depth.cols()));
+}
+// :128-145
+void TsdfVolume::raycast(const Affine3f& camera_pose, const Intr& intr, Cloud& points, Normals& normals)
+{
+  const RaycastPose rp = raycast_pose(pose_, camera_pose);
+  const float in[4] = { intr.fx, intr.fy, intr.cx, intr.cy };
+  yakhip_volume v = make_view(data_.ptr<void>(), dims_, getVoxelSize(), trunc_dist_, max_weight_);
+  YAK_CHECK(yakhip_raycast_points(context(), &v, rp.R, rp.t, rp.Rinv, in, raycast_step_factor_, gradient_delta_factor_,
+                                  points.ptr(), points.step(), normals.ptr(), normals.step(), points.rows(),
+                                  points.cols()));
 }
 DeviceArray<Point> TsdfVolume::fetchCloud(DeviceArray<Point>&) const
 {
@@ -216,6 +252,38 @@ void computeDists(const Depth& depth, Dists& dists, const Intr& intr)  // imgpro
   const float in[4] = { intr.fx, intr.fy, intr.cx, intr.cy };
   YAK_CHECK(yakhip_compute_dists(context(), depth.ptr(), depth.step(), dists.ptr(), dists.step(), depth.rows(),
                                  depth.cols(), in));
+}
+void depthBilateralFilter(const Depth& in, Depth& out, int ksz, float sigma_spatial, float sigma_depth)  // imgproc.cpp:3-11
+{
+  out.create(in.rows(), in.cols());
+  YAK_CHECK(yakhip_bilateral_filter(context(), in.ptr(), in.step(), out.ptr(), out.step(), in.rows(), in.cols(), ksz,
+                                    sigma_spatial, sigma_depth));
+}
+void depthTruncation(Depth& depth, float threshold)  // imgproc.cpp:13
+{
+  YAK_CHECK(yakhip_truncate_depth(context(), depth.ptr(), depth.step(), depth.rows(), depth.cols(), threshold));
+}
+void depthBuildPyramid(const Depth& depth, Depth& pyramid, float sigma_depth)  // imgproc.cpp:15-19
+{
+  pyramid.create(depth.rows() / 2, depth.cols() / 2);
+  YAK_CHECK(yakhip_depth_pyramid(context(), depth.ptr(), depth.step(), depth.rows(), depth.cols(), pyramid.ptr(),
+                                 pyramid.step(), sigma_depth));
+}
+void computePointNormals(const Intr& intr, const Depth& depth, Cloud& points, Normals& normals)  // imgproc.cpp:33-43
+{
+  points.create(depth.rows(), depth.cols());
+  normals.create(depth.rows(), depth.cols());
+  const float in[4] = { intr.fx, intr.fy, intr.cx, intr.cy };
+  YAK_CHECK(yakhip_compute_points_normals(context(), in, depth.ptr(), depth.step(), depth.rows(), depth.cols(),
+                                          points.ptr(), points.step(), normals.ptr(), normals.step()));
+}
+void resizePointsNormals(const Cloud& points, const Normals& normals, Cloud& points_out, Normals& normals_out)
+{  // imgproc.cpp:65-80
+  points_out.create(points.rows() / 2, points.cols() / 2);
+  normals_out.create(normals.rows() / 2, normals.cols() / 2);
+  YAK_CHECK(yakhip_resize_points_normals(context(), points.ptr(), points.step(), normals.ptr(), normals.step(),
+                                         points.rows(), points.cols(), points_out.ptr(), points_out.step(),
+                                         normals_out.ptr(), normals_out.step()));
 }
 void waitAllDefaultStream() { YAK_CHECK(yakhip_ctx_synchronize(context())); }  // imgproc.cpp:21
 }  // namespace cuda
