@@ -88,7 +88,7 @@ const char* yakhip_last_error(void);
 int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value);
 /* Measurement aid with no counterpart in the reference (its only timers are the never-invoked
  * ScopeTime/SampledScopeTime, yak/src/kfusion/core.cpp:236-260).  After
- * yakhip_ctx_set_option(ctx, "kernel_timing", 1) every integrate / raycast kernel launch is bracketed by a
+ * yakhip_ctx_set_option(ctx, "kernel_timing", 1) every integrate / raycast / marching-cubes kernel launch is bracketed by a
  * hipEvent pair on the context's stream; this call waits for them, returns the summed device time of
  * those launches (milliseconds) and their count, and restarts the accumulation. */
 int yakhip_ctx_kernel_time(yakhip_ctx* ctx, double* total_ms, int* launches);
@@ -198,6 +198,25 @@ int yakhip_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], c
                           const void* ncurr_dev, size_t ncurr_pitch, const void* vprev_dev, size_t vprev_pitch,
                           const void* nprev_dev, size_t nprev_pitch, int rows, int cols, float sums_host[27],
                           int counts_host[6]);
+
+/* ---- surface extraction -------------------------------------------------- */
+
+/* GPU counterpart of yak::marchingCubesCPU's core (yak/src/mc/marching_cubes.cpp:22-194: getOffset,
+ * processCube and the triple loop of makeMesh; case table yak/src/mc/marching_cubes_tables.cpp).
+ * Every cube whose 8 corners lie inside the slab's layers [z0, z1) and carry weight >= min_weight
+ * (weight read as UNSIGNED 16 bit, tsdf_container.h:45-49) is triangulated at iso level 0 of
+ * 5 * tsdf.  A triangle is 9 floats {v0.xyz, v1.xyz, v2.xyz} in voxel units times `scale`
+ * (MarchingCubesParameters::scale, yak/include/yak/mc/marching_cubes.h:9-16), z counted from layer 0
+ * of the whole volume.  BLOCKING.  *n_triangles_host always receives the number of triangles the
+ * slab produces; they are written only if triangles_dev != NULL and capacity_triangles is large enough
+ * -- call once with NULL to size the buffer, or pass a generous one and compare.
+ * The triangle SET equals the CPU routine's; the order is this library's (deterministic: by tile, z,
+ * x, case-table order), the reference's being nondeterministic (OpenMP critical section, :163-171).
+ * Multi-GPU: give each rank's slab one extra layer of overlap (z1 = next slab's z0 + 1) and the
+ * per-rank sets are disjoint and complete.  No vertex merging here (MarchingCubesParameters::clean is
+ * VTK's vtkCleanPolyData in the reference, :204-216; the host layer does it). */
+int yakhip_marching_cubes(yakhip_ctx* ctx, const yakhip_volume* vol, int min_weight, double scale, void* triangles_dev,
+                          unsigned long long capacity_triangles, unsigned long long* n_triangles_host);
 
 #ifdef __cplusplus
 }

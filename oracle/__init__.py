@@ -81,6 +81,8 @@ def lib():
         L.yko_icp_accumulate.restype = None
         L.yko_icp_accumulate.argtypes = [_f32p, _f32p, _f32p, i, f, f, vp, sz, vp, sz, vp, sz, vp, sz, i, i,
                                          np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), _u64p, vp]
+        L.yko_marching_cubes.restype = C.c_uint64
+        L.yko_marching_cubes.argtypes = [_u32p, _i32p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.yko_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -242,6 +244,53 @@ def icp_accumulate(R, t, intr, level, dist_thres, angle_thres, vcurr, ncurr, vpr
                              np_.ctypes.data, cols * 16, rows, cols, sums, counts,
                              codes.ctypes.data if codes is not None else None)
     return (sums, counts, codes) if want_codes else (sums, counts)
+
+
+def mc_tables():
+    """(tri_table int32[256,16], edge_connections int32[12,2], source): the reference's own compiled
+    arrays when oracle/_ref is built, otherwise the product's packed table unpacked."""
+    R = ref()
+    if R is not None:
+        tri = np.ctypeslib.as_array(R.yakref_triangle_table(), shape=(256 * 16,)).astype(np.int32).reshape(256, 16)
+        conn = np.ctypeslib.as_array(R.yakref_edge_connections(), shape=(24,)).astype(np.int32).reshape(12, 2)
+        return tri, conn, "reference"
+    tri, conn = unpack_case_table()
+    return tri, conn, "packed"
+
+
+def unpack_case_table():
+    """yak_amd/csrc/mc_case_table.h parsed back into the classic 256 x 16 / 12 x 2 integer arrays."""
+    import re
+
+    text = open(os.path.join(os.path.dirname(_HERE), "yak_amd", "csrc", "mc_case_table.h")).read()
+    body = text[text.index("yak_mc_case_table[256]"):]
+    words = [int(w, 16) for w in re.findall(r"0x([0-9a-f]{16})ull", body)]
+    assert len(words) == 256
+    tri = np.full((256, 16), -1, dtype=np.int32)
+    for c, w in enumerate(words):
+        for k in range(3 * (w >> 60)):
+            tri[c, k] = (w >> (4 * k)) & 0xF
+    pairs = re.findall(r"\{ (\d+), (\d+) \}", text[text.index("yak_mc_edge_corners"):])
+    conn = np.array([[int(a), int(b)] for a, b in pairs], dtype=np.int32)
+    assert conn.shape == (12, 2)
+    return tri, conn
+
+
+def marching_cubes(volume, dims, min_weight=4, scale=1.0, tables=None):
+    """Returns triangles float32 (n, 3, 3) in the reference's serial visiting order."""
+    dims = np.ascontiguousarray(dims, dtype=np.int32)
+    vol = np.ascontiguousarray(volume, dtype=np.uint32).reshape(-1)
+    assert vol.size == int(dims[0]) * int(dims[1]) * int(dims[2])
+    tri, conn = (tables if tables is not None else mc_tables()[:2])
+    tri = np.ascontiguousarray(tri, dtype=np.int32)
+    conn = np.ascontiguousarray(conn, dtype=np.int32)
+    n = lib().yko_marching_cubes(vol, dims, int(min_weight), float(scale), tri.ctypes.data, conn.ctypes.data, None, 0)
+    out = np.empty((n, 3, 3), dtype=np.float32)
+    if n:
+        m = lib().yko_marching_cubes(vol, dims, int(min_weight), float(scale), tri.ctypes.data, conn.ctypes.data,
+                                     out.ctypes.data, n)
+        assert m == n
+    return out
 
 
 def max_threads():

@@ -715,6 +715,86 @@ void yko_icp_accumulate(const float R[9], const float t[3], const float intr[4],
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Marching cubes: src/mc/marching_cubes.cpp.
+ * ------------------------------------------------------------------------------------------ */
+/* :22-31 */
+static float mc_get_offset(float value1, float value2, float value_desired)
+{
+  const double delta = value2 - value1;
+  if (delta == 0.0)
+    return 0.5f;
+  return (float)((value_desired - value1) / delta);
+}
+
+/* :33-37 */
+static const int mc_cube_offsets[8][3] = {
+  { 1, 1, 0 }, { 1, 0, 0 }, { 0, 0, 0 }, { 0, 1, 0 }, { 1, 1, 1 }, { 1, 0, 1 }, { 0, 0, 1 }, { 0, 1, 1 },
+};
+
+uint64_t yko_marching_cubes(const uint32_t* volume, const int dims[3], int min_weight, double scale,
+                            const int* tri_table, const int* edge_connections, float* triangles, uint64_t capacity)
+{
+  const int X = dims[0], Y = dims[1], Z = dims[2];
+  uint64_t n = 0;
+  for (int x = 0; x + 1 < X; ++x) /* :164-170 with x-1, y-1, z-1 */
+    for (int y = 0; y + 1 < Y; ++y)
+      for (int z = 0; z + 1 < Z; ++z)
+      {
+        /* processCube, :39-156 */
+        float val[8];
+        int ok = 1;
+        for (int c = 0; c < 8 && ok; ++c)
+        {
+          const size_t idx = (size_t)X * (size_t)Y * (size_t)(z + mc_cube_offsets[c][2]) +
+                             (size_t)X * (size_t)(y + mc_cube_offsets[c][1]) + (size_t)(x + mc_cube_offsets[c][0]);
+          const uint32_t word = volume[idx];
+          const int w = (int)(uint16_t)(word >> 16); /* uint16_t weight, tsdf_container.h:45-49 */
+          val[c] = 5.0f * yko_half2float((uint16_t)(word & 0xffffu)); /* :46 */
+          if (w < min_weight)
+            ok = 0; /* :51-74 */
+        }
+        if (!ok)
+          continue;
+        unsigned cubeindex = 0; /* :80-96, isolevel 0 */
+        for (int c = 0; c < 8; ++c)
+          if (val[c] < 0.0f)
+            cubeindex |= 1u << c;
+        /* :101-106 edge flags: an edge is cut iff its end corners differ in sign */
+        int edge_flags = 0;
+        for (int e = 0; e < 12; ++e)
+          if (((cubeindex >> edge_connections[2 * e]) & 1u) != ((cubeindex >> edge_connections[2 * e + 1]) & 1u))
+            edge_flags |= 1 << e;
+        if (edge_flags == 0)
+          continue;
+        float edges[12][3];
+        for (int e = 0; e < 12; ++e) /* :112-131 */
+          if (edge_flags & (1 << e))
+          {
+            const int v0 = edge_connections[2 * e], v1 = edge_connections[2 * e + 1];
+            const float offset = mc_get_offset(val[v0], val[v1], 0.0f);
+            const int base[3] = { x, y, z };
+            for (int k = 0; k < 3; ++k)
+            {
+              const float p0 = (float)(base[k] + mc_cube_offsets[v0][k]), p1 = (float)(base[k] + mc_cube_offsets[v1][k]);
+              edges[e][k] = p0 + offset * (p1 - p0);
+            }
+          }
+        const int* triangulation = tri_table + 16 * cubeindex; /* :136-153 */
+        for (int i = 0; i < 5; ++i)
+        {
+          if (triangulation[i * 3] < 0)
+            break;
+          if (n < capacity)
+            for (int j = 0; j < 3; ++j)
+              for (int k = 0; k < 3; ++k) /* :175-183 */
+                triangles[n * 9 + (uint64_t)(3 * j + k)] = (float)(scale * (double)edges[triangulation[i * 3 + j]][k]);
+          ++n;
+        }
+      }
+  return n;
+}
+
 int yko_max_threads(void)
 {
 #ifdef _OPENMP

@@ -120,6 +120,19 @@ void yko_icp_accumulate(const float R[9], const float t[3], const float intr[4],
                         size_t nprev_pitch_bytes, int rows, int cols, double sums[27], uint64_t counts[6],
                         uint8_t* codes);
 
+/*
+ * ---- marching cubes: src/mc/marching_cubes.cpp:22-194 (getOffset, cubeOffsets, processCube, makeMesh) ----
+ * PINNED by the reference's dipyramid known answer (test/marching_cubes_tests.cpp:86-150).
+ * volume: X*Y*Z voxel words (TSDFContainer layout, tsdf_container.h:23-27, 45-49; weight UNSIGNED here).
+ * tri_table: 256 x 16 ints, edge_connections: 12 x 2 ints -- the reference's own arrays when
+ * oracle/_ref is built (src/mc/marching_cubes_tables.cpp), handed in by the caller.
+ * Cubes are visited x outer, y, z inner (the serial order of makeMesh's loops, :164-170); each triangle
+ * is 9 floats {v0.xyz, v1.xyz, v2.xyz}, each coordinate (float)(scale * (double)v) as makeMesh +
+ * vtk2mesh store it (:175-183).  Writes at most `capacity` triangles; returns the number found.
+ */
+uint64_t yko_marching_cubes(const uint32_t* volume, const int dims[3], int min_weight, double scale,
+                            const int* tri_table, const int* edge_connections, float* triangles, uint64_t capacity);
+
 int yko_max_threads(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,120 @@
+"""GPU parity: yakhip_marching_cubes (through the C ABI) against the CPU oracle, which the reference's
+dipyramid known answer pins (tests/test_oracle_mc.py).  Bar: the same triangle SET, bit for bit
+(the reference's own emission order is nondeterministic)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+import oracle  # noqa: E402
+from test_oracle_mc import DIPYRAMID_VERTICES, clean, sphere_volume  # noqa: E402
+from yak_amd import capi, synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def canon(tris):
+    """Order-free form of a triangle list: rows of 9 float bit patterns, sorted."""
+    rows = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 9).view(np.uint32)
+    return rows[np.lexsort(rows.T[::-1])]
+
+
+def gpu_mc(ctx, vol_dev, dims, min_weight, scale=1.0, z0=0, z1=None, slack=0):
+    desc = capi.volume_desc(vol_dev.data_ptr(), dims, (1, 1, 1), 1.0, 64, z0, z1)
+    n = ctx.marching_cubes(desc, min_weight, scale)                       # count only
+    buf = torch.full((max(n + slack, 1), 9), 7.0, dtype=torch.float32, device="cuda")
+    m = ctx.marching_cubes(desc, min_weight, scale, buf.data_ptr(), n + slack)
+    assert m == n
+    out = buf.cpu().numpy()
+    assert (out[n:] == 7.0).all()                                         # nothing beyond the count is written
+    return out[:n].reshape(-1, 3, 3)
+
+
+def test_mc_dipyramid_reference_known_answer(gpu_ctx):
+    vol = np.full(27, 0x00013C00, dtype=np.uint32)
+    vol[13] = 0x0001BC00
+    tris = gpu_mc(gpu_ctx, torch.from_numpy(vol.view(np.int32)).cuda(), (3, 3, 3), 1, 0.01, slack=3)
+    assert tris.shape == (8, 3, 3)                                        # test/marching_cubes_tests.cpp:121
+    verts, faces = clean(tris)
+    assert len(verts) == 6 and len(faces) == 8                            # :133
+    assert np.array_equal(verts, DIPYRAMID_VERTICES[np.lexsort(DIPYRAMID_VERTICES.T[::-1])])
+    assert np.array_equal(canon(tris), canon(oracle.marching_cubes(vol, (3, 3, 3), 1, 0.01)))
+
+
+@pytest.mark.parametrize("n,r,scale", [(64, 20.3, 1.0), (130, 51.7, 0.005859375), (256, 25.6, 0.01)])
+def test_mc_sphere_c1(gpu_ctx, n, r, scale):
+    vol = sphere_volume(n, r)
+    want = oracle.marching_cubes(vol, (n, n, n), 4, scale)
+    got = gpu_mc(gpu_ctx, torch.from_numpy(vol.view(np.int32)).cuda(), (n, n, n), 4, scale)
+    assert len(got) == len(want) > 5000
+    assert np.array_equal(canon(got), canon(want))
+
+
+def fused(n, frames):
+    dims, vs, tr = synth.volume_geometry(n)
+    vol = np.zeros(int(np.prod(dims)), dtype=np.uint32)
+    for f in frames:
+        depth, R, t = synth.scene_s2(f)
+        oracle.integrate(vol, dims, vs, tr, synth.MAX_WEIGHT, oracle.compute_dists(depth, synth.INTR), R, t, synth.INTR,
+                         nthreads=8)
+    return vol, dims
+
+
+@pytest.mark.parametrize("min_weight", [1, 3, 6])
+def test_mc_fused_scene_weights(gpu_ctx, min_weight):
+    vol, dims = fused((96, 80, 112), [0, 20, 40, 60, 80, 100])
+    want = oracle.marching_cubes(vol, dims, min_weight, 3.0 / 96)
+    got = gpu_mc(gpu_ctx, torch.from_numpy(vol.view(np.int32)).cuda(), dims, min_weight, 3.0 / 96)
+    assert len(want) > (1000 if min_weight < 6 else 0)
+    assert len(got) == len(want) and np.array_equal(canon(got), canon(want))
+
+
+def test_mc_slabs_with_one_layer_overlap_tile_the_volume(gpu_ctx):
+    vol, dims = fused(64, [0, 75, 150, 225])
+    plane = dims[0] * dims[1]
+    dev = torch.from_numpy(vol.view(np.int32)).cuda()
+    whole = gpu_mc(gpu_ctx, dev, dims, 1)
+    parts = []
+    for z0, z1 in [(0, 17), (16, 41), (40, 64)]:                          # slab k ends one layer into slab k + 1
+        parts.append(gpu_mc(gpu_ctx, dev[z0 * plane:], dims, 1, z0=z0, z1=z1))
+    assert sum(len(p) for p in parts) == len(whole) > 1000
+    assert np.array_equal(canon(np.concatenate(parts)), canon(whole))
+    assert np.array_equal(canon(whole), canon(oracle.marching_cubes(vol, dims, 1)))
+
+
+def test_mc_capacity_and_degenerate_volumes(gpu_ctx):
+    vol = sphere_volume(32, 9.5)
+    dev = torch.from_numpy(vol.view(np.int32)).cuda()
+    desc = capi.volume_desc(dev.data_ptr(), (32, 32, 32), (1, 1, 1), 1.0, 64)
+    n = gpu_ctx.marching_cubes(desc, 4, 1.0)
+    assert n == len(oracle.marching_cubes(vol, (32, 32, 32), 4))
+    buf = torch.full((n, 9), 7.0, dtype=torch.float32, device="cuda")
+    assert gpu_ctx.marching_cubes(desc, 4, 1.0, buf.data_ptr(), n - 1) == n   # too small: count comes back ...
+    assert (buf == 7.0).all().item()                                            # ... and nothing is written
+    # no cube fits in a single layer / row / column
+    one = capi.volume_desc(dev.data_ptr(), (32, 32, 32), (1, 1, 1), 1.0, 64, 5, 6)
+    assert gpu_ctx.marching_cubes(one, 1, 1.0) == 0
+    flat = capi.volume_desc(dev.data_ptr(), (1024, 1, 32), (1, 1, 1), 1.0, 64)
+    assert gpu_ctx.marching_cubes(flat, 1, 1.0) == 0
+    assert gpu_ctx.marching_cubes(desc, 5, 1.0) == 0                            # every weight is 4
+    with pytest.raises(capi.YakHipError):
+        gpu_ctx.marching_cubes(desc, 4, 1.0, buf.data_ptr() + 2, n)           # misaligned output
+
+
+def test_mc_512_volume_fused_on_gpu(gpu_ctx):
+    n = 512
+    dims, vs, tr = synth.volume_geometry(n)
+    vol = torch.zeros(n ** 3, dtype=torch.int32, device="cuda")
+    desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT)
+    d_dists = torch.empty((synth.ROWS, synth.COLS), dtype=torch.int16, device="cuda")
+    for f in (0, 30, 60, 90, 120):
+        depth, R, t = synth.scene_s2(f)
+        d_depth = torch.from_numpy(depth.view(np.int16)).cuda()
+        gpu_ctx.compute_dists(d_depth.data_ptr(), synth.COLS * 2, d_dists.data_ptr(), synth.COLS * 2, synth.ROWS,
+                              synth.COLS, synth.INTR)
+        gpu_ctx.integrate(desc, d_dists.data_ptr(), synth.COLS * 2, synth.ROWS, synth.COLS, R.reshape(-1), t, synth.INTR)
+    torch.cuda.synchronize()
+    got = gpu_mc(gpu_ctx, vol, dims, 2, vs[0])
+    want = oracle.marching_cubes(vol.cpu().numpy().view(np.uint32), dims, 2, vs[0])
+    assert len(got) == len(want) > 100000
+    assert np.array_equal(canon(got), canon(want))

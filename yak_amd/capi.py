@@ -19,7 +19,7 @@ EXPORTS = [
     "yakhip_clear_volume", "yakhip_compute_dists", "yakhip_integrate",
     "yakhip_raycast_points", "yakhip_raycast_depth",
     "yakhip_bilateral_filter", "yakhip_truncate_depth", "yakhip_depth_pyramid", "yakhip_compute_points_normals",
-    "yakhip_resize_points_normals", "yakhip_icp_accumulate",
+    "yakhip_resize_points_normals", "yakhip_icp_accumulate", "yakhip_marching_cubes",
 ]
 
 
@@ -85,6 +85,7 @@ def load():
         "yakhip_depth_pyramid": [vp, vp, sz, i, i, vp, sz, C.c_float],
         "yakhip_compute_points_normals": [vp, fp, vp, sz, i, i, vp, sz, vp, sz],
         "yakhip_resize_points_normals": [vp, vp, sz, vp, sz, i, i, vp, sz, vp, sz],
+        "yakhip_marching_cubes": [vp, volp, i, C.c_double, vp, C.c_ulonglong, C.POINTER(C.c_ulonglong)],
         "yakhip_icp_accumulate": [vp, fp, fp, fp, i, C.c_float, C.c_float, vp, sz, vp, sz, vp, sz, vp, sz, i, i, fp,
                                   C.POINTER(i)],
     }
@@ -219,6 +220,13 @@ class Context:
                                           ncurr_pitch, C.c_void_p(vprev_ptr), vprev_pitch, C.c_void_p(nprev_ptr),
                                           nprev_pitch, rows, cols, sums, counts))
         return list(sums), list(counts)
+
+    def marching_cubes(self, vol, min_weight, scale, triangles_ptr=0, capacity=0):
+        """Blocking.  Returns the number of triangles the slab produces (written iff it fits `capacity`)."""
+        n = C.c_ulonglong(0)
+        _chk(load().yakhip_marching_cubes(self._h, C.byref(vol), int(min_weight), float(scale),
+                                          C.c_void_p(triangles_ptr or 0), int(capacity), C.byref(n)))
+        return n.value
 
 
 def volume_desc(data_ptr, dims, voxel_size, trunc_dist, max_weight, z0=0, z1=None):

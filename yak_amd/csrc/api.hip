@@ -127,6 +127,9 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->icp_scratch = nullptr;
   ctx->icp_scratch_bytes = 0;
   ctx->icp_pinned = nullptr;
+  ctx->mc_scratch = nullptr;
+  ctx->mc_scratch_bytes = 0;
+  ctx->mc_pinned = nullptr;
   ctx->kernel_timing = 0;
   ctx->timing_used = 0;
   int rc = check(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
@@ -154,6 +157,10 @@ int yakhip_ctx_destroy(yakhip_ctx* ctx)
       (void)hipFree(ctx->icp_scratch);
     if (ctx->icp_pinned)
       (void)hipHostFree(ctx->icp_pinned);
+    if (ctx->mc_scratch)
+      (void)hipFree(ctx->mc_scratch);
+    if (ctx->mc_pinned)
+      (void)hipHostFree(ctx->mc_pinned);
     for (auto& ev : ctx->timing_events)
     {
       (void)hipEventDestroy(ev.first);
@@ -638,6 +645,25 @@ int yakhip_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], c
   return launch_icp_accumulate(ctx, R, t, intr, level, dist_thres, angle_thres, (const uint8_t*)vcurr_dev, vcurr_pitch,
                                (const uint8_t*)ncurr_dev, ncurr_pitch, (const uint8_t*)vprev_dev, vprev_pitch,
                                (const uint8_t*)nprev_dev, nprev_pitch, rows, cols, sums_host, counts_host);
+}
+
+// ---- surface extraction ------------------------------------------------------------------------
+
+int yakhip_marching_cubes(yakhip_ctx* ctx, const yakhip_volume* vol, int min_weight, double scale, void* triangles_dev,
+                          unsigned long long capacity_triangles, unsigned long long* n_triangles_host)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_volume(vol)) != 0)
+    return rc;
+  if (!n_triangles_host)
+    return fail(YAKHIP_EINVAL, "marching_cubes: null count pointer");
+  if (triangles_dev && (uintptr_t)triangles_dev % 4 != 0)
+    return fail(YAKHIP_EALIGN, "marching_cubes: triangle buffer must be 4-byte aligned");
+  return launch_marching_cubes(ctx, (const uint32_t*)vol->data, vol->dims[0], vol->dims[1], vol->z0, vol->z1 - vol->z0,
+                               min_weight, scale, (float*)triangles_dev, triangles_dev ? capacity_triangles : 0,
+                               n_triangles_host);
 }
 
 }  // extern "C"

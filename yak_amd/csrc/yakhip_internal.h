@@ -24,6 +24,9 @@ struct yakhip_ctx
   void* icp_scratch;   // ICP: workgroup partials + the reduced 33 values (device)
   size_t icp_scratch_bytes;
   void* icp_pinned;    // ICP: pinned host mirror of the 33 values
+  void* mc_scratch;    // marching cubes: tile counts, tile offsets, total (device)
+  size_t mc_scratch_bytes;
+  void* mc_pinned;     // marching cubes: pinned host copy of the total
   int kernel_timing;   // record a hipEvent pair around every integrate_kernel launch
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_events;
   size_t timing_used;
@@ -120,6 +123,11 @@ int launch_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], c
                           float dist_thres, float angle_thres, const uint8_t* vcurr, size_t vcurr_pitch,
                           const uint8_t* ncurr, size_t ncurr_pitch, const uint8_t* vprev, size_t vprev_pitch,
                           const uint8_t* nprev, size_t nprev_pitch, int rows, int cols, float sums[27], int counts[6]);
+
+// mc.hip (blocking).  `vol` points at layer z0; `layers` voxel layers are present, so layers - 1 cube
+// layers are meshed.  Only counts when triangles == nullptr or the count exceeds `capacity`.
+int launch_marching_cubes(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int z0, int layers, int min_weight,
+                          double scale, float* triangles, unsigned long long capacity, unsigned long long* n_out);
 
 // ---- device helpers shared by kernels --------------------------------------------------------
 __device__ __forceinline__ float half_bits_to_float(uint32_t bits)
