@@ -132,6 +132,25 @@ int yakhip_compute_dists(yakhip_ctx* ctx, const void* depth_dev, size_t depth_pi
 int yakhip_integrate(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dists_dev, size_t dists_pitch, int rows,
                      int cols, const float R[9], const float t[3], const float intr[4]);
 
+/* One camera frame of a batch: its ray-distance image (as yakhip_compute_dists writes it), vol2cam pose
+ * and intrinsics -- the arguments kfusion::device::integrate takes per frame (internal.hpp:126). */
+typedef struct yakhip_frame
+{
+  const void* dists;   /* device pointer, IEEE half bits */
+  size_t dists_pitch;  /* bytes */
+  int rows, cols;
+  float R[9], t[3];    /* vol2cam, row-major R */
+  float intr[4];       /* fx, fy, cx, cy */
+} yakhip_frame;
+
+/* Multi-camera batched integrate (no single counterpart in the reference, which
+ * integrates one frame per call: yak/src/cuda/tsdf_volume.cu:119-140).  Folds n_frames frames into
+ * every voxel of the slab in the order given, during one sweep of the volume per group of up to 4
+ * frames: each touched voxel is read and written once per group instead of once per frame.  The result
+ * is bit-identical to calling yakhip_integrate n_frames times in that order.  All frames of a call
+ * must have the same image size.  n_frames >= 1. */
+int yakhip_integrate_batch(yakhip_ctx* ctx, const yakhip_volume* vol, const yakhip_frame* frames, int n_frames);
+
 /* ---- ray casting ------------------------------------------------------- */
 
 /* Replaces kfusion::device::raycast, Points overload (internal.hpp:137-144;

@@ -16,7 +16,7 @@ EXPORTS = [
     "yakhip_ctx_kernel_time", "yakhip_selftest_division",
     "yakhip_malloc", "yakhip_malloc_pitch", "yakhip_free", "yakhip_upload", "yakhip_download",
     "yakhip_upload_2d", "yakhip_download_2d",
-    "yakhip_clear_volume", "yakhip_compute_dists", "yakhip_integrate",
+    "yakhip_clear_volume", "yakhip_compute_dists", "yakhip_integrate", "yakhip_integrate_batch",
     "yakhip_raycast_points", "yakhip_raycast_depth",
     "yakhip_bilateral_filter", "yakhip_truncate_depth", "yakhip_depth_pyramid", "yakhip_compute_points_normals",
     "yakhip_resize_points_normals", "yakhip_icp_accumulate", "yakhip_marching_cubes",
@@ -39,6 +39,19 @@ class VolumeDesc(C.Structure):
         ("voxel_size", C.c_float * 3),
         ("trunc_dist", C.c_float),
         ("max_weight", C.c_int),
+    ]
+
+
+class FrameDesc(C.Structure):
+    """struct yakhip_frame"""
+    _fields_ = [
+        ("dists", C.c_void_p),
+        ("dists_pitch", C.c_size_t),
+        ("rows", C.c_int),
+        ("cols", C.c_int),
+        ("R", C.c_float * 9),
+        ("t", C.c_float * 3),
+        ("intr", C.c_float * 4),
     ]
 
 
@@ -78,6 +91,7 @@ def load():
         "yakhip_clear_volume": [vp, volp],
         "yakhip_compute_dists": [vp, vp, sz, vp, sz, i, i, fp],
         "yakhip_integrate": [vp, volp, vp, sz, i, i, fp, fp, fp],
+        "yakhip_integrate_batch": [vp, volp, C.POINTER(FrameDesc), i],
         "yakhip_raycast_points": [vp, volp, fp, fp, fp, fp, C.c_float, C.c_float, vp, sz, vp, sz, i, i],
         "yakhip_raycast_depth": [vp, volp, fp, fp, fp, fp, C.c_float, C.c_float, vp, sz, vp, sz, i, i],
         "yakhip_bilateral_filter": [vp, vp, sz, vp, sz, i, i, i, C.c_float, C.c_float],
@@ -173,6 +187,16 @@ class Context:
     def integrate(self, vol, dists_ptr, dists_pitch, rows, cols, R, t, intr):
         _chk(load().yakhip_integrate(self._h, C.byref(vol), C.c_void_p(dists_ptr), dists_pitch, rows, cols,
                                      _f32(R, 9), _f32(t, 3), _f32(intr, 4)))
+
+    def integrate_batch(self, vol, frames):
+        """frames: sequence of (dists_ptr, dists_pitch, rows, cols, R, t, intr), applied in order."""
+        arr = (FrameDesc * len(frames))()
+        for d, (ptr, pitch, rows, cols, R, t, intr) in zip(arr, frames):
+            d.dists, d.dists_pitch, d.rows, d.cols = ptr, pitch, rows, cols
+            d.R[:] = [float(v) for v in R]
+            d.t[:] = [float(v) for v in t]
+            d.intr[:] = [float(v) for v in intr]
+        _chk(load().yakhip_integrate_batch(self._h, C.byref(vol), arr, len(frames)))
 
     def raycast_points(self, vol, R, t, Rinv, intr, points_ptr, points_pitch, normals_ptr, normals_pitch, rows, cols,
                        step_factor=0.75, gradient_delta_factor=0.5):

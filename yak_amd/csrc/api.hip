@@ -418,14 +418,10 @@ int yakhip_compute_dists(yakhip_ctx* ctx, const void* depth_dev, size_t depth_pi
                               cols, intr[0], intr[1], intr[2], intr[3]);
 }
 
-int yakhip_integrate(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dists_dev, size_t dists_pitch, int rows,
-                     int cols, const float R[9], const float t[3], const float intr[4])
+static int fill_integrate_params(IntegrateParams& p, const yakhip_volume* vol, const void* dists_dev, size_t dists_pitch,
+                                 int rows, int cols, const float R[9], const float t[3], const float intr[4])
 {
-  int rc = enter(ctx);
-  if (rc != 0)
-    return rc;
-  if ((rc = check_volume(vol)) != 0)
-    return rc;
+  int rc;
   if (!R || !t || !intr)
     return fail(YAKHIP_EINVAL, "integrate: null pose or intrinsics");
   if ((rc = check_image("integrate(dists)", dists_dev, dists_pitch, rows, cols, 2)) != 0)
@@ -436,11 +432,13 @@ int yakhip_integrate(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dist
   if (!(vol->trunc_dist > 0.f))
     return fail(YAKHIP_EINVAL, "integrate: trunc_dist must be positive");
 
-  IntegrateParams p;
   p.vol = (uint32_t*)vol->data;
   p.dists = (const uint8_t*)dists_dev;
   p.thr = nullptr;  // thr, coarse, cw/ch and the grp_* constants are filled by the launcher
   p.coarse = nullptr;
+  p.cw = p.ch = 0;
+  p.grp_enable = 0;
+  p.grp_margin = p.grp_cols_hi = p.grp_rows_hi = p.grp_span = p.grp_inv_bk = p.grp_bias = p.grp_zmin = 0.f;
   p.dists_pitch = (uint32_t)dists_pitch;
   p.rows = rows;
   p.cols = cols;
@@ -463,7 +461,43 @@ int yakhip_integrate(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dist
   p.fy = intr[1];
   p.cx = intr[2];
   p.cy = intr[3];
+  return 0;
+}
+
+int yakhip_integrate(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dists_dev, size_t dists_pitch, int rows,
+                     int cols, const float R[9], const float t[3], const float intr[4])
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_volume(vol)) != 0)
+    return rc;
+  IntegrateParams p;
+  if ((rc = fill_integrate_params(p, vol, dists_dev, dists_pitch, rows, cols, R, t, intr)) != 0)
+    return rc;
   return launch_integrate(ctx, p);
+}
+
+int yakhip_integrate_batch(yakhip_ctx* ctx, const yakhip_volume* vol, const yakhip_frame* frames, int n_frames)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_volume(vol)) != 0)
+    return rc;
+  if (!frames || n_frames < 1)
+    return fail(YAKHIP_EINVAL, "integrate_batch: needs at least one frame");
+  std::vector<IntegrateParams> ps((size_t)n_frames);
+  for (int i = 0; i < n_frames; ++i)
+  {
+    const yakhip_frame& f = frames[i];
+    if ((rc = fill_integrate_params(ps[(size_t)i], vol, f.dists, f.dists_pitch, f.rows, f.cols, f.R, f.t, f.intr)) != 0)
+      return rc;
+    if (f.rows != frames[0].rows || f.cols != frames[0].cols)
+      return fail(YAKHIP_EINVAL, "integrate_batch: frame %d is %d x %d, frame 0 is %d x %d", i, f.cols, f.rows,
+                  frames[0].cols, frames[0].rows);
+  }
+  return launch_integrate_batch(ctx, ps.data(), n_frames);
 }
 
 static int raycast_common(yakhip_ctx* ctx, const yakhip_volume* vol, const float R[9], const float t[3],

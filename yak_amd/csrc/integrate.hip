@@ -386,23 +386,21 @@ __device__ __forceinline__ void buf_store(typename Vec<VX>::type v, rsrc_t rs, u
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int, v), rs, voff, soff, aux);
   else
     __builtin_amdgcn_raw_buffer_store_b32(v, rs, voff, soff, aux);
+  // A 16-byte store reads its data VGPRs for some cycles after issue.  hipcc's hazard recogniser exempts
+  // buffer stores whose soffset is an SGPR, and in the batched kernel it placed a v_cndmask into the
+  // first data register right behind such a store: on gfx950 that value, not the voxel, reached memory
+  // (512^3, timing dependent, only the lanes read last).  The asm keeps the data registers live -- so
+  // nothing may be allocated over them -- until the idle states have passed.
+  if constexpr (VX == 4)
+    asm volatile("s_nop 7" ::"v"(v));
 }
 
-// Stage 2 of layer z: settle every voxel, fuse, write back; then fetch the voxels two layers ahead
-// into the same register buffer.
-//   soff        byte offset of this layer inside the chunk's buffer
-//   ahead_ok    the layer two steps on is still inside the chunk
-template <int VX, bool NT>
-__device__ __forceinline__ void update(const IntegrateParams& p, const Pos<VX>& c, const Probe<VX>& pr,
-                                       typename Vec<VX>::type& buf, mask_t& buf_valid, rsrc_t rs, uint32_t voff,
-                                       uint32_t soff, uint32_t layer_bytes, bool live, bool ahead_ok,
-                                       uint32_t max_w_hi)
+// Decide every voxel of a lane's run at one layer from what stage 1 left: which voxels take an update
+// (hit), which of those with a measurement of exactly 1.0 (unit), and the measurement (tsdf).
+template <int VX>
+__device__ __forceinline__ void settle(const IntegrateParams& p, const Pos<VX>& c, const Probe<VX>& pr, mask_t live_m,
+                                       mask_t (&hit)[VX], mask_t (&unit)[VX], float (&tsdf)[VX])
 {
-  typedef typename Vec<VX>::type vec_t;
-  mask_t hit[VX], unit[VX];
-  float tsdf[VX];
-  mask_t hit_any = 0;
-  const mask_t live_m = live ? ~0ull : 0ull;
 #pragma unroll
   for (int v = 0; v < VX; ++v)
   {
@@ -449,23 +447,14 @@ __device__ __forceinline__ void update(const IntegrateParams& p, const Pos<VX>& 
       }
     }
   }
-#pragma unroll
-  for (int v = 0; v < VX; ++v)
-    hit_any |= hit[v];
+}
 
-  // the reference reads only updated voxels (tsdf_volume.cu:98-100): demand-load what the look-ahead
-  // did not bring (first two layers of a chunk, and lanes whose updates start at this layer)
-  const mask_t need = hit_any & ~buf_valid;
-  if (need != 0)  // wave-uniform, rare after the first trips
-  {
-    const vec_t got = buf_load<VX, NT>(rs, lanes(need) ? voff : kNoAccess, soff);
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): settle here so the hot path keeps its counted waits
-#pragma unroll
-    for (int v = 0; v < VX; ++v)
-      vset<VX>(buf, v, lanes(need) ? vget<VX>(got, v) : vget<VX>(buf, v));
-  }
-
-  vec_t out = buf;
+// Fold one measurement per voxel into the packed voxels `buf` -> `out` (tsdf_volume.cu:98-106).
+template <int VX>
+__device__ __forceinline__ void fuse_run(const typename Vec<VX>::type& buf, typename Vec<VX>::type& out,
+                                         const mask_t (&hit)[VX], const mask_t (&unit)[VX], const float (&tsdf)[VX],
+                                         int max_weight, uint32_t max_w_hi)
+{
   mask_t general[VX];
   mask_t general_any = 0;
 #pragma unroll
@@ -486,8 +475,43 @@ __device__ __forceinline__ void update(const IntegrateParams& p, const Pos<VX>& 
 #pragma unroll
     for (int v = 0; v < VX; ++v)
       if (lanes(general[v]))
-        vset<VX>(out, v, fuse(vget<VX>(buf, v), tsdf[v], p.max_weight));
+        vset<VX>(out, v, fuse(vget<VX>(buf, v), tsdf[v], max_weight));
   }
+}
+
+// Stage 2 of layer z: settle every voxel, fuse, write back; then fetch the voxels two layers ahead
+// into the same register buffer.
+//   soff        byte offset of this layer inside the chunk's buffer
+//   ahead_ok    the layer two steps on is still inside the chunk
+template <int VX, bool NT>
+__device__ __forceinline__ void update(const IntegrateParams& p, const Pos<VX>& c, const Probe<VX>& pr,
+                                       typename Vec<VX>::type& buf, mask_t& buf_valid, rsrc_t rs, uint32_t voff,
+                                       uint32_t soff, uint32_t layer_bytes, bool live, bool ahead_ok,
+                                       uint32_t max_w_hi)
+{
+  typedef typename Vec<VX>::type vec_t;
+  mask_t hit[VX], unit[VX];
+  float tsdf[VX];
+  mask_t hit_any = 0;
+  settle<VX>(p, c, pr, live ? ~0ull : 0ull, hit, unit, tsdf);
+#pragma unroll
+  for (int v = 0; v < VX; ++v)
+    hit_any |= hit[v];
+
+  // the reference reads only updated voxels (tsdf_volume.cu:98-100): demand-load what the look-ahead
+  // did not bring (first two layers of a chunk, and lanes whose updates start at this layer)
+  const mask_t need = hit_any & ~buf_valid;
+  if (need != 0)  // wave-uniform, rare after the first trips
+  {
+    const vec_t got = buf_load<VX, NT>(rs, lanes(need) ? voff : kNoAccess, soff);
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): settle here so the hot path keeps its counted waits
+#pragma unroll
+    for (int v = 0; v < VX; ++v)
+      vset<VX>(buf, v, lanes(need) ? vget<VX>(got, v) : vget<VX>(buf, v));
+  }
+
+  vec_t out = buf;
+  fuse_run<VX>(buf, out, hit, unit, tsdf, p.max_weight, max_w_hi);
   buf_store<VX, NT>(out, rs, lanes(hit_any) ? voff : kNoAccess, soff);
 
   // look-ahead: updates are coherent along z, so a lane that updated this layer will very likely
@@ -603,22 +627,25 @@ static int launch_variant(yakhip_ctx* ctx, const IntegrateParams& p, dim3 grid)
   return check(hipGetLastError(), "integrate_kernel launch");
 }
 
-int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in)
+// Per-frame set-up shared by the single-frame and the batched launch: the prepass kernel (band
+// thresholds + coarse minima) into slot `slot` of the context's scratch, and the group-test constants.
+// All slots of one launch have the same geometry (same image size, same coarse cap).
+static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slots, size_t coarse_cap_bytes)
 {
-  IntegrateParams p = p_in;
-  const uintptr_t base = (uintptr_t)p.vol;
-
   // ---- per-frame prepass into context-owned scratch: per-pixel band thresholds (8 B/pixel) and
   //      the coarse minima the group test looks up (one float per bk x bk pixel cell) ----
   int bk = 8;
-  while (((p.cols + bk - 1) / bk) * ((p.rows + bk - 1) / bk) * (int)sizeof(float) > 32768 && bk < 1024)
+  while ((size_t)((p.cols + bk - 1) / bk) * ((p.rows + bk - 1) / bk) * sizeof(float) > coarse_cap_bytes && bk < 1024)
     bk *= 2;
   p.cw = (p.cols + bk - 1) / bk;
   p.ch = (p.rows + bk - 1) / bk;
   const size_t thr_bytes = (size_t)p.rows * (size_t)p.cols * sizeof(f32x2);
   const size_t coarse_bytes = (size_t)p.cw * p.ch * sizeof(float);
-  if (ctx->thr_bytes < thr_bytes + coarse_bytes)
+  const size_t slot_bytes = (thr_bytes + coarse_bytes + 255u) & ~(size_t)255u;
+  if (ctx->thr_bytes < slot_bytes * (size_t)slots)
   {
+    if (slot != 0)
+      return fail(YAKHIP_EINVAL, "integrate: frames of one batch must have the same image size");
     if (ctx->thr)
     {
       YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -626,18 +653,19 @@ int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in)
       ctx->thr = nullptr;
       ctx->thr_bytes = 0;
     }
-    YAKHIP_TRY(hipMalloc(&ctx->thr, thr_bytes + coarse_bytes));
-    ctx->thr_bytes = thr_bytes + coarse_bytes;
+    YAKHIP_TRY(hipMalloc(&ctx->thr, slot_bytes * (size_t)slots));
+    ctx->thr_bytes = slot_bytes * (size_t)slots;
   }
-  p.thr = (const f32x2*)ctx->thr;
-  p.coarse = (const float*)((const char*)ctx->thr + thr_bytes);
+  char* base = (char*)ctx->thr + slot_bytes * (size_t)slot;
+  p.thr = (const f32x2*)base;
+  p.coarse = (const float*)(base + thr_bytes);
   {
     const uint32_t thr_blocks_x = (uint32_t)((p.cols + 255) / 256);
     const uint32_t thr_blocks = thr_blocks_x * (uint32_t)p.rows;
     const uint32_t cell_blocks = (uint32_t)((p.cw * p.ch + 3) / 4);
     hipLaunchKernelGGL(prepass_kernel, dim3(thr_blocks + cell_blocks), dim3(256), 0, ctx->stream, p.dists,
-                       p.dists_pitch, p.rows, p.cols, p.trunc_hi, (f32x2*)ctx->thr, (float*)p.coarse, p.cw, p.ch, bk,
-                       thr_blocks_x, thr_blocks);
+                       p.dists_pitch, p.rows, p.cols, p.trunc_hi, (f32x2*)base, (float*)(base + thr_bytes), p.cw, p.ch,
+                       bk, thr_blocks_x, thr_blocks);
     YAKHIP_TRY(hipGetLastError());
   }
 
@@ -665,30 +693,21 @@ int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in)
     p.grp_zmin = fmaxf(f * P * 0x1p-15f, 0x1p-10f);
     // the test assumes an ordinary pinhole (positive focal lengths, image below 32k px) and finite pose
     p.grp_enable = ctx->group_test && p.fx > 0.f && p.fy > 0.f && p.cols < 32768 && p.rows < 32768 &&
-                   std::isfinite(P) && std::isfinite(f) && coarse_bytes <= 32768;
+                   std::isfinite(P) && std::isfinite(f) && coarse_bytes <= coarse_cap_bytes;
   }
+  return 0;
+}
 
-  // widest vector the layout allows: rows must not straddle a lane's group and the slab base,
-  // every row start and every layer start must be aligned to the vector size
-  int vx = 1;
-  if (p.X % 4 == 0 && base % 16 == 0)
-    vx = 4;
-  else if (p.X % 2 == 0 && base % 8 == 0)
-    vx = 2;
-  if (ctx->force_vx > 0 && ctx->force_vx < vx)
-    vx = ctx->force_vx;
-
-  const uint32_t groups = p.plane / (uint32_t)vx;
-  const uint32_t blocks_x = (groups + 255u) / 256u;
+// z_chunk and grid for a plane of `blocks_x` workgroups: the kernel is software-pipelined, so two or
+// three 4-wave workgroups per CU already saturate HBM; longer chunks mean less replay of layers
+// [0, zs) and fewer prologues, shorter ones balance scenes whose cost varies across the volume.
+static int choose_chunk(const yakhip_ctx* ctx, const IntegrateParams& p, uint32_t blocks_x, uint32_t want_blocks,
+                        int* chunk_out, uint32_t* nchunks_out)
+{
   const int layers = p.z1 - p.z0;
-
-  // z_chunk: the kernel is software-pipelined, so two or three 4-wave workgroups per CU already
-  // saturate HBM; longer chunks mean less replay of layers [0, zs) and fewer prologues, shorter ones
-  // balance scenes whose cost varies across the volume.  Aim for ~3 workgroups per CU.
   int chunk = ctx->z_chunk;
   if (chunk <= 0)
   {
-    const uint32_t want_blocks = 768u;
     uint32_t nchunks = (want_blocks + blocks_x - 1u) / blocks_x;
     if (nchunks < 1u)
       nchunks = 1u;
@@ -705,10 +724,39 @@ int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in)
     return fail(YAKHIP_ERANGE, "integrate: one z layer exceeds 2 GiB");
   if ((uint64_t)chunk > max_chunk)
     chunk = (int)max_chunk;
-  p.z_chunk = chunk;
   const uint32_t nchunks = (uint32_t)((layers + chunk - 1) / chunk);
   if (nchunks > 65535u)
     return fail(YAKHIP_ERANGE, "integrate: %u z-chunks exceed the grid limit; raise z_chunk", nchunks);
+  *chunk_out = chunk;
+  *nchunks_out = nchunks;
+  return 0;
+}
+
+int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in)
+{
+  IntegrateParams p = p_in;
+  const uintptr_t base = (uintptr_t)p.vol;
+  int rc = prepare_frame(ctx, p, 0, 1, 32768);
+  if (rc != 0)
+    return rc;
+
+  // widest vector the layout allows: rows must not straddle a lane's group and the slab base,
+  // every row start and every layer start must be aligned to the vector size
+  int vx = 1;
+  if (p.X % 4 == 0 && base % 16 == 0)
+    vx = 4;
+  else if (p.X % 2 == 0 && base % 8 == 0)
+    vx = 2;
+  if (ctx->force_vx > 0 && ctx->force_vx < vx)
+    vx = ctx->force_vx;
+
+  const uint32_t groups = p.plane / (uint32_t)vx;
+  const uint32_t blocks_x = (groups + 255u) / 256u;
+  int chunk = 0;
+  uint32_t nchunks = 0;
+  if ((rc = choose_chunk(ctx, p, blocks_x, 768u, &chunk, &nchunks)) != 0)
+    return rc;
+  p.z_chunk = chunk;
 
   const dim3 grid(blocks_x, nchunks);
   switch (vx)
@@ -720,6 +768,208 @@ int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in)
     default:
       return launch_variant<1>(ctx, p, grid);
   }
+}
+
+// ---- multi-camera batched integrate ---------------------------------------------------------------
+// K frames (each with its own ray-distance image, pose and intrinsics) are folded into every voxel in
+// frame order k = 0..K-1 during ONE sweep of the volume: the voxel is read once and written once
+// (8 B per touched voxel instead of 8 B per frame), and the result is bit-identical to K consecutive
+// yakhip_integrate calls because each frame's measurement depends only on the voxel's position and
+// that frame's image, and the running average is applied in the same order.  (Extension of
+// tsdf_volume.cu:51-110)
+//
+// Same lane layout, exact replay, group test, band thresholds and buffer addressing as the
+// single-frame kernel; per layer the K frames are settled one after the other while the voxels of
+// the next layer are already in flight.
+constexpr int kBatchMax = 4;
+struct BatchParams
+{
+  IntegrateParams f[kBatchMax];  // f[k].vol / X / Y / z0 / z1 / z_chunk / plane / voxel sizes / trunc agree
+};
+
+template <int K, bool NT>
+__global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchParams bp)
+{
+  constexpr int VX = 4;
+  typedef Vec<VX>::type vec_t;
+  extern __shared__ __attribute__((aligned(16))) float coarse_lds[];
+  const IntegrateParams& p = bp.f[0];
+
+  const int cells = p.cw * p.ch;  // the same for every frame: same image size, same cell size
+  if (p.grp_enable)
+  {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      for (int i = (int)threadIdx.x; i < cells; i += 256)
+        coarse_lds[k * cells + i] = bp.f[k].coarse[i];
+    __syncthreads();
+  }
+
+  const uint32_t group = blockIdx.x * 256u + threadIdx.x;
+  if (group >= p.plane / VX)
+    return;
+  const mask_t active = ballot(true);
+  const uint32_t elem = group * VX;
+  const int y = (int)(elem / (uint32_t)p.X);
+  const int x0 = (int)(elem - (uint32_t)y * (uint32_t)p.X);
+  const int zs = p.z0 + (int)blockIdx.y * p.z_chunk;
+  const int ze = min(zs + p.z_chunk, p.z1);
+
+  Pos<VX> pos[K];
+  const float vxy = (float)y * p.vsy;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+  {
+    const IntegrateParams& f = bp.f[k];
+#pragma unroll
+    for (int j = 0; j < Pos<VX>::NP; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+      {
+        const float vxx = (float)(x0 + Pos<VX>::voxel(j, h)) * p.vsx;
+        pos[k].x[j][h] = dot3(f.R[0], f.R[1], f.R[2], vxx, vxy, 0.f) + f.t[0];
+        pos[k].y[j][h] = dot3(f.R[3], f.R[4], f.R[5], vxx, vxy, 0.f) + f.t[1];
+        pos[k].z[j][h] = dot3(f.R[6], f.R[7], f.R[8], vxx, vxy, 0.f) + f.t[2];
+      }
+    // replay of the reference's per-layer additions on [0, zs), per frame (tsdf_volume.cu:69, 76)
+    const float zx = f.R[2] * p.vsz, zy = f.R[5] * p.vsz, zz = f.R[8] * p.vsz;
+    const f32x2 sx = { zx, zx }, sy = { zy, zy }, sz = { zz, zz };
+    for (int i = 0; i < zs; ++i)
+      advance<VX>(pos[k], pos[k], sx, sy, sz);
+  }
+
+  const uint32_t max_w_hi = ((uint32_t)p.max_weight << 16) | 0xffffu;
+  const uint32_t layer_bytes = p.plane * 4u;
+  const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.vol + (size_t)(zs - p.z0) * p.plane, 0,
+                                                      (uint32_t)(ze - zs) * layer_bytes, 0x00020000);
+  const uint32_t voff = elem * 4u;
+
+  mask_t have = ~0ull;  // lanes whose `cur` holds this layer's voxels
+  vec_t cur = buf_load<VX, NT>(rs, voff, 0u);
+  uint32_t soff = 0;
+  for (int z = zs; z < ze; ++z, soff += layer_bytes)
+  {
+    vec_t out = cur;
+    mask_t any = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+    {
+      const IntegrateParams& f = bp.f[k];
+      const f32x2 fx2 = { f.fx, f.fx }, fy2 = { f.fy, f.fy }, cx2 = { f.cx, f.cx }, cy2 = { f.cy, f.cy };
+      Probe<VX> pr;
+      stage1<VX>(f, pos[k], pr, coarse_lds + k * cells, active, fx2, fy2, cx2, cy2);
+      mask_t hit[VX], unit[VX];
+      float tsdf[VX];
+      settle<VX>(f, pos[k], pr, ~0ull, hit, unit, tsdf);
+      const mask_t hk = hit[0] | hit[1] | hit[2] | hit[3];
+      // only updated voxels are read (tsdf_volume.cu:98-100): fetch what the look-ahead did not bring.
+      // A lane that needs it has not been touched by an earlier frame of this layer, so `out` is free.
+      const mask_t need = hk & ~have;
+      if (need != 0)  // wave-uniform
+      {
+        const vec_t got = buf_load<VX, NT>(rs, lanes(need) ? voff : kNoAccess, soff);
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+#pragma unroll
+        for (int v = 0; v < VX; ++v)
+          vset<VX>(out, v, lanes(need) ? vget<VX>(got, v) : vget<VX>(out, v));
+        have |= need;
+      }
+      if (hk != 0)  // wave-uniform
+      {
+        const vec_t prev = out;
+        fuse_run<VX>(prev, out, hit, unit, tsdf, p.max_weight, max_w_hi);
+      }
+      any |= hk;
+      const float zx = f.R[2] * p.vsz, zy = f.R[5] * p.vsz, zz = f.R[8] * p.vsz;
+      advance<VX>(pos[k], pos[k], f32x2{ zx, zx }, f32x2{ zy, zy }, f32x2{ zz, zz });
+    }
+    buf_store<VX, NT>(out, rs, lanes(any) ? voff : kNoAccess, soff);
+    // look-ahead: a lane that updated this layer very likely updates the next one
+    have = z + 1 < ze ? any : 0;
+    cur = buf_load<VX, NT>(rs, lanes(have) ? voff : kNoAccess, soff + layer_bytes);
+  }
+}
+
+template <int K>
+static int launch_batch_variant(yakhip_ctx* ctx, const BatchParams& bp, dim3 grid, size_t lds)
+{
+  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  int rc = timing_begin(ctx, &ev);
+  if (rc != 0)
+    return rc;
+  if (ctx->nontemporal)
+    hipLaunchKernelGGL((integrate_batch_kernel<K, true>), grid, dim3(256), lds, ctx->stream, bp);
+  else
+    hipLaunchKernelGGL((integrate_batch_kernel<K, false>), grid, dim3(256), lds, ctx->stream, bp);
+  if ((rc = timing_end(ctx, ev)) != 0)
+    return rc;
+  return check(hipGetLastError(), "integrate_batch_kernel launch");
+}
+
+int launch_integrate_batch(yakhip_ctx* ctx, const IntegrateParams* frames, int n_frames)
+{
+  // the wide layout is the only one the batched kernel has; anything else (and a lone frame) goes
+  // through the single-frame kernel, frame by frame -- the same result by definition
+  const IntegrateParams& p0 = frames[0];
+  const bool wide = p0.X % 4 == 0 && (uintptr_t)p0.vol % 16 == 0 && ctx->force_vx != 1 && ctx->force_vx != 2;
+  int done = 0;
+  while (done < n_frames)
+  {
+    const int k = wide ? (n_frames - done < kBatchMax ? n_frames - done : kBatchMax) : 1;
+    if (k == 1)
+    {
+      const int rc = launch_integrate(ctx, frames[done]);
+      if (rc != 0)
+        return rc;
+      done += 1;
+      continue;
+    }
+    BatchParams bp;
+    const size_t coarse_cap = 32768 / (size_t)k;  // all K coarse images share the workgroup's LDS
+    for (int i = 0; i < k; ++i)
+    {
+      bp.f[i] = frames[done + i];
+      if (bp.f[i].rows != p0.rows || bp.f[i].cols != p0.cols)
+        return fail(YAKHIP_EINVAL, "integrate_batch: frames must have the same image size");
+      const int rc = prepare_frame(ctx, bp.f[i], i, k, coarse_cap);
+      if (rc != 0)
+        return rc;
+    }
+    for (int i = k; i < kBatchMax; ++i)
+      bp.f[i] = bp.f[0];
+    // the group test is per workgroup: on for the batch only if every frame allows it
+    bool grp = true;
+    for (int i = 0; i < k; ++i)
+      grp = grp && bp.f[i].grp_enable;
+    for (int i = 0; i < kBatchMax; ++i)
+      bp.f[i].grp_enable = grp;
+    const uint32_t blocks_x = (p0.plane / 4u + 255u) / 256u;
+    int chunk = 0;
+    uint32_t nchunks = 0;
+    int rc = choose_chunk(ctx, bp.f[0], blocks_x, 1024u, &chunk, &nchunks);
+    if (rc != 0)
+      return rc;
+    for (int i = 0; i < kBatchMax; ++i)
+      bp.f[i].z_chunk = chunk;
+    const dim3 grid(blocks_x, nchunks);
+    const size_t lds = grp ? (size_t)k * bp.f[0].cw * bp.f[0].ch * sizeof(float) : 0;
+    switch (k)
+    {
+      case 2:
+        rc = launch_batch_variant<2>(ctx, bp, grid, lds);
+        break;
+      case 3:
+        rc = launch_batch_variant<3>(ctx, bp, grid, lds);
+        break;
+      default:
+        rc = launch_batch_variant<4>(ctx, bp, grid, lds);
+        break;
+    }
+    if (rc != 0)
+      return rc;
+    done += k;
+  }
+  return 0;
 }
 
 // ---- self-test of the division building blocks (yakhip_selftest_division) -----------------------

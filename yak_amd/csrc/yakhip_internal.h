@@ -100,6 +100,8 @@ struct RaycastParams
 };
 
 int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p);
+// n_frames >= 1 frames applied in order to the same slab; thr / coarse / grp_* / z_chunk are filled here
+int launch_integrate_batch(yakhip_ctx* ctx, const IntegrateParams* frames, int n_frames);
 int launch_raycast(yakhip_ctx* ctx, const RaycastParams& p);
 int launch_clear(const yakhip_ctx* ctx, uint32_t* data, size_t n_voxels);
 int launch_selftest_division(yakhip_ctx* ctx, unsigned long long counts[4]);
