@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--scene", default="s0", choices=["s0", "s1"], help="s1 = sphere+wall (partial updates); N=1 only")
     ap.add_argument("--z-chunk", type=int, default=0)
     ap.add_argument("--vx", type=int, default=0, help="cap on voxels per lane (tuning)")
+    ap.add_argument("--tile", type=int, default=0, help="wave footprint: log2 lanes along x, 3..6 (tuning)")
     ap.add_argument("--zu", type=int, default=0, help="layers per loop trip (tuning)")
     ap.add_argument("--no-nt", action="store_true", help="plain instead of non-temporal volume accesses (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -145,6 +146,8 @@ def main():
         ctx.set_option("z_chunk", args.z_chunk)
     if args.vx:
         ctx.set_option("vx", args.vx)
+    if args.tile:
+        ctx.set_option("tile", args.tile)
     if args.zu:
         ctx.set_option("zu", args.zu)
     if args.no_nt:

@@ -122,6 +122,7 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->force_vx = 0;
   ctx->zu = 0;
   ctx->group_test = 1;
+  ctx->tile_shift = 0;
   ctx->thr = nullptr;
   ctx->thr_bytes = 0;
   ctx->icp_scratch = nullptr;
@@ -230,6 +231,13 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
   if (strcmp(key, "group_test") == 0)
   {
     ctx->group_test = value != 0;
+    return 0;
+  }
+  if (strcmp(key, "tile") == 0)
+  {
+    if (value != 0 && (value < 3 || value > 6))
+      return fail(YAKHIP_EINVAL, "tile must be 0 (default) or 3..6");
+    ctx->tile_shift = value;
     return 0;
   }
   if (strcmp(key, "zu") == 0)
@@ -447,6 +455,7 @@ static int fill_integrate_params(IntegrateParams& p, const yakhip_volume* vol, c
   p.z0 = vol->z0;
   p.z1 = vol->z1;
   p.z_chunk = 0;
+  p.tile_shift = 6;
   p.plane = (uint32_t)vol->dims[0] * (uint32_t)vol->dims[1];
   p.vsx = vol->voxel_size[0];
   p.vsy = vol->voxel_size[1];

@@ -38,6 +38,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
+constexpr int kDefaultTileShift = 6;  // wave footprint in a layer, see lane_voxels()
+
 template <int VX>
 struct Vec;
 template <>
@@ -520,6 +522,35 @@ __device__ __forceinline__ void update(const IntegrateParams& p, const Pos<VX>& 
   buf = buf_load<VX, NT>(rs, lanes(buf_valid) ? voff : kNoAccess, soff + 2u * layer_bytes);
 }
 
+// Which voxels of a layer a lane owns.  tile_shift == 6: lanes in layer order, a wave = 64 * VX voxels of
+// one x-row.  Smaller shifts fold the wave into a compact tile -- 2^shift lanes (2^shift * VX voxels,
+// still >= 128 contiguous bytes) along x times 64 >> shift rows, the four waves of a workgroup stacked
+// in y -- so that a surface cutting through the layer sends fewer waves down the per-voxel path
+// (a wave takes it as soon as ONE lane is not settled by the group test).
+template <int VX>
+__device__ __forceinline__ bool lane_voxels(const IntegrateParams& p, uint32_t& elem, int& x0, int& y)
+{
+  if (p.tile_shift >= 6)
+  {
+    const uint32_t group = blockIdx.x * 256u + threadIdx.x;  // VX-voxel group inside one z layer
+    if (group >= p.plane / VX)
+      return false;
+    elem = group * VX;
+    y = (int)(elem / (uint32_t)p.X);
+    x0 = (int)(elem - (uint32_t)y * (uint32_t)p.X);
+    return true;
+  }
+  // the launcher only picks a tile that divides the layer: every lane owns voxels
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t lanes_x = 1u << p.tile_shift, rows_wave = 64u >> p.tile_shift;
+  const uint32_t blocks_per_row = (uint32_t)p.X / (lanes_x * VX);
+  const uint32_t bx = blockIdx.x % blocks_per_row, by = blockIdx.x / blocks_per_row;
+  x0 = (int)((bx * lanes_x + (lane & (lanes_x - 1u))) * VX);
+  y = (int)(by * 4u * rows_wave + wave * rows_wave + (lane >> p.tile_shift));
+  elem = (uint32_t)y * (uint32_t)p.X + (uint32_t)x0;
+  return true;
+}
+
 // VX voxels per lane along x.  The z loop is software-pipelined two layers deep with two register
 // sets (A, B): while layer z is being settled and written, layer z+1 is already tested/projected
 // (its threshold gathers in flight), and the voxels of layers z+1 / z+2 are being fetched.
@@ -538,13 +569,11 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
     __syncthreads();
   }
 
-  const uint32_t group = blockIdx.x * 256u + threadIdx.x;  // VX-voxel group inside one z layer
-  if (group >= p.plane / VX)
+  uint32_t elem;  // x + y*X of the lane's first voxel; X % VX == 0 so no row straddle
+  int x0, y;
+  if (!lane_voxels<VX>(p, elem, x0, y))
     return;
   const mask_t active = ballot(true);
-  const uint32_t elem = group * VX;  // x + y*X of the first voxel; X % VX == 0 so no row straddle
-  const int y = (int)(elem / (uint32_t)p.X);
-  const int x0 = (int)(elem - (uint32_t)y * (uint32_t)p.X);
 
   const int zs = p.z0 + (int)blockIdx.y * p.z_chunk;
   const int ze = min(zs + p.z_chunk, p.z1);
@@ -698,22 +727,24 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
   return 0;
 }
 
-// z_chunk and grid for a plane of `blocks_x` workgroups: the kernel is software-pipelined, so two or
-// three 4-wave workgroups per CU already saturate HBM; longer chunks mean less replay of layers
-// [0, zs) and fewer prologues, shorter ones balance scenes whose cost varies across the volume.
+// z_chunk and grid for a plane of `blocks_x` workgroups.  Short chunks balance the load: the cost of a
+// chunk depends on how much surface it holds (per-voxel path, band arithmetic), and with a few long
+// chunks per column the last workgroups of a surface-rich frame run alone (measured at 512^3: 171-layer
+// chunks 0.61 ms on the orbit scene, 32-layer chunks 0.29 ms; the wall scene is 0.193 ms either way).
+// What limits shortening is the replay of layers [0, zs), which grows with the chunk count: keep at most
+// 16 chunks per column, at least 32 layers each, unless the grid would be too small to fill the chip.
 static int choose_chunk(const yakhip_ctx* ctx, const IntegrateParams& p, uint32_t blocks_x, uint32_t want_blocks,
-                        int* chunk_out, uint32_t* nchunks_out)
+                        int min_chunk, int* chunk_out, uint32_t* nchunks_out)
 {
   const int layers = p.z1 - p.z0;
   int chunk = ctx->z_chunk;
   if (chunk <= 0)
   {
-    uint32_t nchunks = (want_blocks + blocks_x - 1u) / blocks_x;
-    if (nchunks < 1u)
-      nchunks = 1u;
-    chunk = (int)((layers + (int)nchunks - 1) / (int)nchunks);
-    if (chunk < 16)
-      chunk = 16;
+    chunk = (layers + 15) / 16;
+    if (chunk < min_chunk)
+      chunk = min_chunk;
+    while (chunk > 16 && (uint64_t)blocks_x * (uint64_t)((layers + chunk - 1) / chunk) < want_blocks)
+      chunk = chunk / 2 < 16 ? 16 : chunk / 2;
   }
   if (chunk > layers)
     chunk = layers;
@@ -730,6 +761,19 @@ static int choose_chunk(const yakhip_ctx* ctx, const IntegrateParams& p, uint32_
   *chunk_out = chunk;
   *nchunks_out = nchunks;
   return 0;
+}
+
+// Largest compact tile (see lane_voxels) that divides the layer exactly; 6 = plain layer order.
+static int choose_tile(const yakhip_ctx* ctx, const IntegrateParams& p, int vx)
+{
+  int shift = ctx->tile_shift > 0 ? ctx->tile_shift : kDefaultTileShift;
+  for (; shift < 6; ++shift)
+  {
+    const uint32_t tile_x = (1u << shift) * (uint32_t)vx, tile_y = 4u * (64u >> shift);
+    if ((uint32_t)p.X % tile_x == 0 && (uint32_t)p.Y % tile_y == 0)
+      break;
+  }
+  return shift;
 }
 
 int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in)
@@ -752,9 +796,10 @@ int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in)
 
   const uint32_t groups = p.plane / (uint32_t)vx;
   const uint32_t blocks_x = (groups + 255u) / 256u;
+  p.tile_shift = choose_tile(ctx, p, vx);
   int chunk = 0;
   uint32_t nchunks = 0;
-  if ((rc = choose_chunk(ctx, p, blocks_x, 768u, &chunk, &nchunks)) != 0)
+  if ((rc = choose_chunk(ctx, p, blocks_x, 768u, 32, &chunk, &nchunks)) != 0)
     return rc;
   p.z_chunk = chunk;
 
@@ -805,13 +850,11 @@ __global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchPara
     __syncthreads();
   }
 
-  const uint32_t group = blockIdx.x * 256u + threadIdx.x;
-  if (group >= p.plane / VX)
+  uint32_t elem;  // x + y*X of the lane's first voxel; X % VX == 0 so no row straddle
+  int x0, y;
+  if (!lane_voxels<VX>(p, elem, x0, y))
     return;
   const mask_t active = ballot(true);
-  const uint32_t elem = group * VX;
-  const int y = (int)(elem / (uint32_t)p.X);
-  const int x0 = (int)(elem - (uint32_t)y * (uint32_t)p.X);
   const int zs = p.z0 + (int)blockIdx.y * p.z_chunk;
   const int ze = min(zs + p.z_chunk, p.z1);
 
@@ -946,11 +989,16 @@ int launch_integrate_batch(yakhip_ctx* ctx, const IntegrateParams* frames, int n
     const uint32_t blocks_x = (p0.plane / 4u + 255u) / 256u;
     int chunk = 0;
     uint32_t nchunks = 0;
-    int rc = choose_chunk(ctx, bp.f[0], blocks_x, 1024u, &chunk, &nchunks);
+    // the batched kernel replays K frames per chunk start: a little longer chunks pay (measured, 512^3)
+    int rc = choose_chunk(ctx, bp.f[0], blocks_x, 1024u, 48, &chunk, &nchunks);
     if (rc != 0)
       return rc;
+    const int tile = choose_tile(ctx, bp.f[0], 4);
     for (int i = 0; i < kBatchMax; ++i)
+    {
       bp.f[i].z_chunk = chunk;
+      bp.f[i].tile_shift = tile;
+    }
     const dim3 grid(blocks_x, nchunks);
     const size_t lds = grp ? (size_t)k * bp.f[0].cw * bp.f[0].ch * sizeof(float) : 0;
     switch (k)

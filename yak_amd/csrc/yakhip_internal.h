@@ -19,6 +19,7 @@ struct yakhip_ctx
   int force_vx;        // 0 = widest the layout allows; 1/2/4 caps the voxels per lane
   int zu;              // (unused; kept for option compatibility)
   int group_test;      // coarse group test on (default) / off
+  int tile_shift;      // 0 = default wave footprint, else 3..6 (tuning)
   void* thr;           // scratch: per-pixel band thresholds of the frame being integrated
   size_t thr_bytes;
   void* icp_scratch;   // ICP: workgroup partials + the reduced 33 values (device)
@@ -70,6 +71,7 @@ struct IntegrateParams
   int X, Y;              // in-plane extent
   int z0, z1;            // owned layers
   int z_chunk;           // layers walked by one workgroup (grid.y index)
+  int tile_shift;        // log2 of the lanes a wave lays along x (6 = layer order); integrate.hip lane_voxels()
   uint32_t plane;        // X * Y
   float vsx, vsy, vsz;
   float trunc, trunc_inv;
