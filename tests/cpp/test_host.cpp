@@ -1,6 +1,7 @@
 // Host-layer tests, in the style the reference tests its own host code (gtest-like cases, no gtest
 // in this image): `test_host --cpu` needs no GPU; `test_host --gpu` drives yak::FusionServer on a
 // real device and checks the downloaded volume word for word against the CPU oracle.
+#include <yak/mc/marching_cubes.h>
 #include <yak/yak_server.h>
 
 #include <yak_oracle.h>
@@ -398,6 +399,41 @@ static void test_kinfu_icp_tracks_orbit()
     EXPECT(after.matrix.val[i] == p.volume_pose.matrix.val[i]);
 }
 
+// The reference's own marching-cubes test, case for case (yak/test/marching_cubes_tests.cpp:86-150):
+// a 3 x 3 x 3 volume of half(1.0), weight 1, with half(-1.0) in the middle, scale 0.01, min_weight 1,
+// clean -> 8 faces over 6 distinct vertices at the positions of the test's PLY text.
+static void test_marching_cubes_dipyramid()
+{
+  std::printf("marchingCubesCPU: the reference's dipyramid known answer\n");
+  yak::TSDFContainer volume(3, 3, 3);
+  for (int i = 0; i < 27; ++i)
+    volume.data()[i] = 0x00013C00u;                      // pack(half(1.0), 1)
+  volume.data()[volume.toIndex(1, 1, 1)] = 0x0001BC00u;  // pack(half(-1.0), 1)
+  yak::MarchingCubesParameters mc;
+  mc.scale = 0.01;
+  mc.min_weight = 1;
+  mc.clean = true;
+  const yak::PolygonMesh mesh = yak::marchingCubesCPU(volume, mc);
+  EXPECT(mesh.polygons.size() == 8);  // :121
+  EXPECT(mesh.cloud.size() == 6);     // :133
+  const double want[6][3] = { { 0.01, 0.005, 0.01 }, { 0.005, 0.01, 0.01 }, { 0.01, 0.01, 0.005 },
+                              { 0.015, 0.01, 0.01 }, { 0.01, 0.01, 0.015 }, { 0.01, 0.015, 0.01 } };  // :24-29
+  for (const auto& w : want)  // :136-149: every baseline vertex has a mesh vertex in its 0.001 octree cell
+  {
+    bool found = false;
+    for (const auto& p : mesh.cloud)
+      found = found || (std::fabs(p[0] - w[0]) < 1e-6 && std::fabs(p[1] - w[1]) < 1e-6 && std::fabs(p[2] - w[2]) < 1e-6);
+    EXPECT(found);
+  }
+  for (const auto& f : mesh.polygons)
+    EXPECT(f[0] < 6 && f[1] < 6 && f[2] < 6 && f[0] != f[1] && f[1] != f[2] && f[0] != f[2]);
+  mc.clean = false;  // marching_cubes.cpp:217-220: three fresh points per triangle
+  const yak::PolygonMesh raw = yak::marchingCubesCPU(volume, mc);
+  EXPECT(raw.polygons.size() == 8 && raw.cloud.size() == 24);
+  mc.min_weight = 2;  // every weight is 1: all cubes dropped (:51-74)
+  EXPECT(yak::marchingCubesCPU(volume, mc).polygons.empty());
+}
+
 static void test_device_arrays()
 {
   std::printf("DeviceArray / DeviceArray2D\n");
@@ -438,6 +474,7 @@ int main(int argc, char** argv)
       test_device_arrays();
       test_fusion_server_against_oracle();
       test_kinfu_icp_tracks_orbit();
+      test_marching_cubes_dipyramid();
     }
   }
   catch (const std::exception& e)

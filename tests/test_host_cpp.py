@@ -29,7 +29,9 @@ def test_frontend_library_exports_reference_class_names():
                  "kfusion::KinFuParams::default_params()", "kfusion::cuda::TsdfVolume::integrate(",
                  "kfusion::cuda::TsdfVolume::clear()", "kfusion::cuda::computeDists(",
                  "kfusion::cuda::DeviceMemory2D::upload(", "kfusion::cuda::getCudaEnabledDeviceCount()",
-                 "yak::TSDFContainer::TSDFContainer(int, int, int)"]:
+                 "yak::TSDFContainer::TSDFContainer(int, int, int)", "yak::marchingCubesCPU(",
+                 "kfusion::cuda::TsdfVolume::raycast(", "kfusion::cuda::ProjectiveICP::estimateTransform(",
+                 "kfusion::cuda::depthBilateralFilter(", "kfusion::cuda::computePointNormals("]:
         assert name in syms, name
 
 

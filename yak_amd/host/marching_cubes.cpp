@@ -1,0 +1,78 @@
+// yak::marchingCubesCPU (reference yak/src/mc/marching_cubes.cpp:158-230): container -> triangles ->
+// mesh.  The triple loop over cubes runs on the GPU; the optional cleaning is done here.
+#include <yak/mc/marching_cubes.h>
+
+#include <yak/kfusion/cuda/device_memory.hpp>
+#include <yakhip.h>
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+namespace yak
+{
+PolygonMesh marchingCubesCPU(const TSDFContainer& tsdf, const MarchingCubesParameters& params)
+{
+  using kfusion::cuda::context;
+  using kfusion::cuda::error;
+  const Vector3i d = tsdf.dims();
+  kfusion::cuda::DeviceMemory vol;
+  vol.upload(tsdf.data(), tsdf.size64() * sizeof(std::uint32_t));
+
+  yakhip_volume v;
+  v.data = vol.ptr<void>();
+  v.dims[0] = d.x(), v.dims[1] = d.y(), v.dims[2] = d.z();
+  v.z0 = 0, v.z1 = d.z();
+  v.voxel_size[0] = v.voxel_size[1] = v.voxel_size[2] = 1.f;  // vertices are in voxel units times params.scale
+  v.trunc_dist = 1.f;
+  v.max_weight = 1;
+
+  unsigned long long n = 0;
+  if (yakhip_marching_cubes(context(), &v, params.min_weight, params.scale, nullptr, 0, &n) != 0)
+    error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_marching_cubes(count)");
+  std::vector<float> tri((size_t)n * 9);
+  if (n)
+  {
+    kfusion::cuda::DeviceMemory out((size_t)n * 9 * sizeof(float));
+    unsigned long long m = 0;
+    if (yakhip_marching_cubes(context(), &v, params.min_weight, params.scale, out.ptr<void>(), n, &m) != 0 || m != n)
+      error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_marching_cubes(emit)");
+    out.download(tri.data());
+  }
+
+  PolygonMesh mesh;
+  if (!params.clean)  // marching_cubes.cpp:217-220: three fresh points per triangle
+  {
+    mesh.cloud.resize((size_t)n * 3);
+    mesh.polygons.resize((size_t)n);
+    for (size_t i = 0; i < (size_t)n * 3; ++i)
+      mesh.cloud[i] = { tri[3 * i], tri[3 * i + 1], tri[3 * i + 2] };
+    for (size_t i = 0; i < (size_t)n; ++i)
+      mesh.polygons[i] = { (std::uint32_t)(3 * i), (std::uint32_t)(3 * i + 1), (std::uint32_t)(3 * i + 2) };
+    return mesh;
+  }
+
+  // :204-216 -- exact point merging (bit patterns), then triangles with a repeated index are dropped
+  const size_t corners = (size_t)n * 3;
+  std::vector<std::uint32_t> order(corners);
+  std::iota(order.begin(), order.end(), 0u);
+  auto key = [&tri](std::uint32_t c) { return &tri[(size_t)c * 3]; };
+  std::sort(order.begin(), order.end(), [&](std::uint32_t a, std::uint32_t b) {
+    return std::memcmp(key(a), key(b), 12) < 0;  // any strict order on bit patterns groups equal points
+  });
+  std::vector<std::uint32_t> index(corners);
+  for (size_t i = 0; i < corners; ++i)
+  {
+    if (i == 0 || std::memcmp(key(order[i]), key(order[i - 1]), 12) != 0)
+      mesh.cloud.push_back({ key(order[i])[0], key(order[i])[1], key(order[i])[2] });
+    index[order[i]] = (std::uint32_t)(mesh.cloud.size() - 1);
+  }
+  for (size_t i = 0; i < (size_t)n; ++i)
+  {
+    const std::uint32_t a = index[3 * i], b = index[3 * i + 1], c = index[3 * i + 2];
+    if (a != b && b != c && a != c)
+      mesh.polygons.push_back({ a, b, c });
+  }
+  return mesh;
+}
+}  // namespace yak
