@@ -78,6 +78,89 @@ def cpu_baseline(dims, vs, tr, dists, R, t, intr, max_weight):
     }
 
 
+def next_rows(ctx, torch, capi, synth, with_cpu):
+    """Secondary measurements, N = 1 only: the SURVEY.md 8f rows that sit either side of the hot path, on a
+    512^3 volume fused from eight views of the S2 orbit scene.  Device times from the library's HIP event
+    pairs around the kernels; never part of `value`."""
+    import math
+
+    n = VOXELS_PER_RANK_EDGE
+    rows, cols, intr = synth.ROWS, synth.COLS, synth.INTR
+    dims, vs, tr = synth.volume_geometry(n)
+    vol = torch.zeros(n ** 3, dtype=torch.int32, device="cuda")
+    desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT)
+    frames, keep = [], []
+    for f in range(0, 300, 38):
+        depth, R, t = synth.scene_s2(f)
+        d = torch.from_numpy(depth.view(np.int16)).cuda()
+        dd = torch.empty_like(d)
+        ctx.compute_dists(d.data_ptr(), cols * 2, dd.data_ptr(), cols * 2, rows, cols, intr)
+        keep.append((d, dd))
+        frames.append((dd.data_ptr(), cols * 2, rows, cols, R.reshape(-1), t, intr))
+
+    def timed(fn, reps):
+        fn()
+        ctx.set_option("kernel_timing", 1)
+        for _ in range(reps):
+            fn()
+        ms, launches = ctx.kernel_time()
+        ctx.set_option("kernel_timing", 0)
+        return ms / reps
+
+    out = {"volume": "512^3 fused from 8 views of the S2 orbit scene (ground plane + 3 spheres)"}
+    # integrate on a surface-rich frame, single and batched (same frames, same result)
+    for a in frames:
+        ctx.integrate(desc, *a)
+    out["integrate_s2_ms_per_frame"] = round(timed(lambda: ctx.integrate(desc, *frames[3]), 10), 4)
+    out["integrate_batch_k4_s2_ms_per_frame"] = round(timed(lambda: ctx.integrate_batch(desc, frames[:4]), 5) / 4, 4)
+
+    # raycast from an orbit pose (cam2vol = inverse of vol2cam)
+    _, R_v2c, t_v2c = synth.scene_s2(19)
+    Rc = np.ascontiguousarray(R_v2c.T)
+    tc = (-(R_v2c.astype(np.float64).T @ t_v2c.astype(np.float64))).astype(np.float32)
+    pts = torch.empty((rows, cols, 4), dtype=torch.float32, device="cuda")
+    nrm = torch.empty_like(pts)
+    ms = timed(lambda: ctx.raycast_points(desc, Rc.reshape(-1), tc, R_v2c.reshape(-1), intr, pts.data_ptr(), cols * 16,
+                                          nrm.data_ptr(), cols * 16, rows, cols), 20)
+    hits = int((~torch.isnan(pts[..., 0])).sum().item())
+    out["raycast"] = {"ms": round(ms, 4), "rays": rows * cols, "hits": hits, "bound": "gather latency"}
+
+    # one ICP linearisation at full resolution: the ray-cast maps against themselves
+    def icp():
+        ctx.icp_accumulate(np.eye(3).reshape(-1), np.zeros(3), intr, 0, 0.1, math.radians(30.0), pts.data_ptr(), cols * 16,
+                           nrm.data_ptr(), cols * 16, pts.data_ptr(), cols * 16, nrm.data_ptr(), cols * 16, rows, cols)
+    icp()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        icp()
+    out["icp_accumulate_level0_ms_blocking"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
+
+    # marching cubes: count pass + scan + emit pass; HBM roofline on 2 reads of the volume + the triangles
+    ntri = ctx.marching_cubes(desc, 2, vs[0])
+    tri = torch.empty((max(ntri, 1), 9), dtype=torch.float32, device="cuda")
+    ms = timed(lambda: ctx.marching_cubes(desc, 2, vs[0], tri.data_ptr(), ntri), 5)
+    mc_bytes = 2 * 4 * n ** 3 + 36 * ntri
+    out["marching_cubes"] = {"ms_both_passes": round(ms, 4), "triangles": ntri, "algorithmic_bytes": mc_bytes,
+                             "achieved_GBps": round(mc_bytes / (ms * 1e-3) / 1e9, 1),
+                             "frac_of_hbm_peak": round(mc_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                             "Gvox_per_s": round(n ** 3 / (ms * 1e-3) / 1e9, 1)}
+    if with_cpu:
+        import oracle
+
+        sub = 128  # bounded sample: the central 128^3 block of the same volume
+        lo = (n - sub) // 2
+        block = vol.view(n, n, n)[lo:lo + sub, lo:lo + sub, lo:lo + sub].contiguous().cpu().numpy().view(np.uint32)
+        t0 = time.perf_counter()
+        cpu_tris = oracle.marching_cubes(block.reshape(-1), (sub, sub, sub), 2, vs[0])
+        dt = time.perf_counter() - t0
+        out["marching_cubes"]["cpu_baseline"] = {
+            "value": round(sub ** 3 / (dt / 2) / 1e9, 4), "unit": "Gvox/s", "cores": 1, "kind": "port",
+            "sample": "oracle restatement of marchingCubesCPU's core on the central 128^3 block (%d triangles), "
+                      "count + emit runs" % len(cpu_tris)}
+    return out
+
+
 def load_traffic(workload_key):
     """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/traffic.json), or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -102,6 +185,7 @@ def main():
     ap.add_argument("--zu", type=int, default=0, help="layers per loop trip (tuning)")
     ap.add_argument("--no-nt", action="store_true", help="plain instead of non-temporal volume accesses (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rows", action="store_true", help="skip the secondary measurements (raycast, ICP, MC, batch)")
     args = ap.parse_args()
 
     import torch
@@ -251,6 +335,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             dists_host = d_dists.cpu().numpy().view(np.uint16)
             out["cpu_baseline"] = cpu_baseline(dims, vs, tr, dists_host, R, t, intr, synth.MAX_WEIGHT)
+        if world == 1 and not args.no_rows and args.scene == "s0":
+            del vol
+            try:
+                out["next_rows"] = next_rows(ctx, torch, capi, synth, not args.no_cpu_baseline)
+            except Exception as e:  # secondary: never take the headline down with it
+                out["next_rows"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out), flush=True)
 
     if dist is not None:

@@ -218,6 +218,32 @@ int yakhip_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], c
                           const void* nprev_dev, size_t nprev_pitch, int rows, int cols, float sums_host[27],
                           int counts_host[6]);
 
+/* One pyramid level of an ICP problem: the current frame's maps, the previous (model) maps, their size
+ * and the number of linearisations to run on it (ProjectiveICP::iters_, projective_icp.cpp:87-96). */
+typedef struct yakhip_icp_level
+{
+  const void *vcurr, *ncurr, *vprev, *nprev; /* float4 maps, device */
+  size_t vcurr_pitch, ncurr_pitch, vprev_pitch, nprev_pitch;
+  int rows, cols;
+  int iterations;
+} yakhip_icp_level;
+
+/* Replaces the body of kfusion::cuda::ProjectiveICP::estimateTransform (Points variant,
+ * yak/src/kfusion/projective_icp.cpp:175-232) in one call: coarse to fine over levels[n_levels-1] .. levels[0]
+ * (levels[l] is pyramid level l: intrinsics divided by 1 << l), `iterations` linearisations each, starting
+ * from the pose R,t (current -> previous camera).  The reference returns to the host after every
+ * linearisation (stream sync, cv::determinant, cv::solve, compose); here accumulation, reduction, the
+ * 6 x 6 solve and the pose update are chained on the device and the host waits once.  The device solve
+ * is a double-precision Cholesky factorisation, used only while it provably equals the reference's
+ * SVD solve (no singular value below OpenCV's cut-off, determinant clear of the 1e-15 test); otherwise
+ * the call repeats the estimate with per-linearisation host solves (LU determinant, Jacobi SVD).
+ * *ok = 0 reproduces estimateTransform returning false (|det| < 1e-15 or NaN): R_out,t_out then hold
+ * the estimate reached before the failing linearisation.  BLOCKING.  Parity of the solve with OpenCV is
+ * unpinned (the reference pins no OpenCV version); see DESIGN.md. */
+int yakhip_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], float dist_thres,
+                        float angle_thres, const yakhip_icp_level* levels, int n_levels, float R_out[9], float t_out[3],
+                        int* ok);
+
 /* ---- surface extraction -------------------------------------------------- */
 
 /* GPU counterpart of yak::marchingCubesCPU's core (yak/src/mc/marching_cubes.cpp:22-194: getOffset,

@@ -6,7 +6,7 @@
 
 #include <yak_oracle.h>
 
-#include "../../yak_amd/host/solve6.hpp"
+#include "../../yak_amd/csrc/solve6.hpp"
 
 #include <cmath>
 #include <cstdio>

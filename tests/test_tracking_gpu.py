@@ -258,3 +258,90 @@ def test_tracking_rejects_bad_arguments(gpu_ctx):
         gpu_ctx.icp_accumulate(np.eye(3).reshape(-1), np.zeros(3), synth.INTR, 99, 0.1, 0.5, f4.data_ptr(), 128,
                                f4.data_ptr(), 128, f4.data_ptr(), 128, f4.data_ptr(), 128, 8, 8)
     assert e.value.code == -1
+
+
+def _gn_loop_python(ctx, dev, shapes, schedule, R0, t0):
+    """The reference's control flow (projective_icp.cpp:195-231) with numpy as the host solver."""
+    R, t = np.array(R0, dtype=np.float64), np.array(t0, dtype=np.float64)
+    for level, iters in schedule:
+        rows, cols = shapes[level]
+        args = []
+        for b in dev[level]:
+            args += [b.data_ptr(), b.stride(0) * 4]
+        for _ in range(iters):
+            sums, _ = ctx.icp_accumulate(np.float32(R).reshape(-1), np.float32(t), synth.INTR, level, 0.1,
+                                         math.radians(30.0), *args, rows, cols)
+            A, b = np.zeros((6, 6)), np.zeros(6)
+            k = 0
+            for i in range(6):
+                for j in range(i, 7):
+                    if j == 6:
+                        b[i] = sums[k]
+                    else:
+                        A[i, j] = A[j, i] = sums[k]
+                    k += 1
+            if abs(np.linalg.det(A)) < 1e-15:
+                return R, t, False
+            r = np.linalg.solve(A, b)
+            rv = np.float32(r[:3]).astype(np.float64)
+            th = np.linalg.norm(rv)
+            K = np.array([[0, -rv[2], rv[1]], [rv[2], 0, -rv[0]], [-rv[1], rv[0], 0]]) / max(th, 1e-300)
+            Rinc = np.float32(np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * K @ K).astype(np.float64)
+            R = np.float32(Rinc @ R).astype(np.float64)
+            t = np.float32(Rinc @ t + np.float32(r[3:])).astype(np.float64)
+    return R, t, True
+
+
+def test_icp_estimate_device_loop_equals_host_loop(gpu_ctx):
+    """yakhip_icp_estimate (all 19 linearisations chained on the device, one wait) against the same
+    schedule driven from the host one linearisation at a time.  The two solvers (device Cholesky, numpy
+    LU) agree to double rounding; poses are compared at 1e-5."""
+    prev = [level_maps(60, l) for l in range(3)]
+    curr = [level_maps(62, l) for l in range(3)]
+    dev = [[dev_f4(a) for a in (curr[l][0], curr[l][1], prev[l][0], prev[l][1])] for l in range(3)]
+    shapes = [curr[l][0].shape[:2] for l in range(3)]
+    levels = [(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[0].stride(0) * 4, shapes[l][0],
+               shapes[l][1], it) for l, (d, it) in enumerate(zip(dev, (4, 5, 10)))]
+    Rd, td, ok = gpu_ctx.icp_estimate(np.eye(3).reshape(-1), np.zeros(3), synth.INTR, 0.1, math.radians(30.0), levels)
+    Rh, th, okh = _gn_loop_python(gpu_ctx, dev, shapes, ((2, 10), (1, 5), (0, 4)), np.eye(3), np.zeros(3))
+    assert ok and okh
+    assert np.abs(np.array(Rd).reshape(3, 3) - Rh).max() < 1e-5 and np.abs(np.array(td) - th).max() < 1e-5
+    # and it is the true motion
+    Rp, tp, Rc, tc = prev[0][2], prev[0][3], curr[0][2], curr[0][3]
+    R_true = Rp @ Rc.T
+    t_true = tp - R_true @ tc
+    assert np.abs(np.array(Rd).reshape(3, 3) - R_true).max() < 2e-3 and np.linalg.norm(np.array(td) - t_true) < 5e-3
+    # a non-identity start (pose hint) and a shorter schedule
+    hint_R, hint_t = R_true, t_true + np.array([0.01, -0.005, 0.008])
+    lv2 = [lv[:7] + (it,) for lv, it in zip(levels, (2, 0, 3))]
+    Rd, td, ok = gpu_ctx.icp_estimate(np.float32(hint_R).reshape(-1), np.float32(hint_t), synth.INTR, 0.1,
+                                      math.radians(30.0), lv2)
+    Rh, th, okh = _gn_loop_python(gpu_ctx, dev, shapes, ((2, 3), (0, 2)), np.float32(hint_R), np.float32(hint_t))
+    assert ok and okh
+    assert np.abs(np.array(Rd).reshape(3, 3) - Rh).max() < 1e-5 and np.abs(np.array(td) - th).max() < 1e-5
+    # deterministic
+    Rd2, td2, _ = gpu_ctx.icp_estimate(np.float32(hint_R).reshape(-1), np.float32(hint_t), synth.INTR, 0.1,
+                                       math.radians(30.0), lv2)
+    assert Rd2 == Rd and td2 == td
+
+
+def test_icp_estimate_degenerate_inputs_take_the_host_path(gpu_ctx):
+    # no data at all: the normal matrix is zero, the reference's determinant test fails the frame
+    p, n, _, _ = level_maps(10, 2)
+    empty = np.full_like(p, np.nan)
+    de, dp, dn = dev_f4(empty), dev_f4(p), dev_f4(n)
+    rows, cols = p.shape[:2]
+    lv = [(de.data_ptr(), de.data_ptr(), dp.data_ptr(), dn.data_ptr(), de.stride(0) * 4, rows, cols, 3)]
+    R0 = np.float32([[0.999, 0, 0.04], [0, 1, 0], [-0.04, 0, 0.999]])
+    Rd, td, ok = gpu_ctx.icp_estimate(R0.reshape(-1), np.float32([0.1, 0.2, 0.3]), synth.INTR, 0.1, 0.5, lv)
+    assert not ok
+    assert np.array_equal(np.float32(Rd).reshape(3, 3), R0) and td == [np.float32(0.1), np.float32(0.2), np.float32(0.3)]
+    # a single fronto-parallel plane constrains 3 of 6 degrees of freedom: singular system; whatever the
+    # determinant's rounding makes of it, the call must come back with a finite pose or ok == False
+    depth = np.full((120, 160), 2000, dtype=np.uint16)
+    pp, pn = oracle.compute_points_normals(depth, tuple(np.float32(v) / 4 for v in synth.INTR))
+    d1, d2 = dev_f4(pp), dev_f4(pn)
+    lv = [(d1.data_ptr(), d2.data_ptr(), d1.data_ptr(), d2.data_ptr(), d1.stride(0) * 4, 120, 160, 2)]
+    # level index 0 with quarter-size maps: pass the matching intrinsics as "level 0"
+    Rd, td, ok = gpu_ctx.icp_estimate(np.eye(3).reshape(-1), np.zeros(3), tuple(v / 4 for v in synth.INTR), 0.1, 0.5, lv)
+    assert (not ok) or (np.isfinite(Rd).all() and np.isfinite(td).all())

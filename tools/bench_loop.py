@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--frames", type=int, default=60)
     ap.add_argument("--no-icp", action="store_true")
+    ap.add_argument("--host-icp", action="store_true", help="one blocking linearisation at a time, numpy solve")
     args = ap.parse_args()
     import torch
 
@@ -44,7 +45,7 @@ def main():
     ctx.clear_volume(desc)
     i16 = lambda r, c: torch.empty((r, c), dtype=torch.int16, device="cuda")        # noqa: E731
     f4 = lambda r, c: torch.empty((r, c, 4), dtype=torch.float32, device="cuda")    # noqa: E731
-    LEVELS, iters = 3, (10, 5, 4)
+    LEVELS, iters = 3, (10, 5, 4)  # iterations on levels 2, 1, 0 (coarse to fine)
     dists = i16(rows, cols)
     cur_d = [i16(rows >> l, cols >> l) for l in range(LEVELS)]
     cur_p = [f4(rows >> l, cols >> l) for l in range(LEVELS)]
@@ -80,24 +81,32 @@ def main():
                                        (cols >> l) * 16, cur_n[l].data_ptr(), (cols >> l) * 16)
         e[1].record()
         if f > 0 and not args.no_icp:
-            R, t = np.eye(3), np.zeros(3)      # current -> previous camera
-            for l in reversed(range(LEVELS)):
-                r_, c_ = rows >> l, cols >> l
-                for _ in range(iters[l]):
-                    sums, _ = ctx.icp_accumulate(np.float32(R).reshape(-1), np.float32(t), intr, l, 0.1, math.radians(30.0),
-                                                 cur_p[l].data_ptr(), c_ * 16, cur_n[l].data_ptr(), c_ * 16,
-                                                 prv_p[l].data_ptr(), c_ * 16, prv_n[l].data_ptr(), c_ * 16, r_, c_)
-                    A, b, k = np.zeros((6, 6)), np.zeros(6), 0
-                    for i in range(6):
-                        for j in range(i, 7):
-                            if j == 6:
-                                b[i] = sums[k]
-                            else:
-                                A[i, j] = A[j, i] = sums[k]
-                            k += 1
-                    x = np.linalg.solve(A, b)
-                    Ri = rodrigues(x[:3])
-                    R, t = Ri @ R, Ri @ t + x[3:]
+            if args.host_icp:
+                R, t = np.eye(3), np.zeros(3)      # current -> previous camera
+                for l in reversed(range(LEVELS)):
+                    r_, c_ = rows >> l, cols >> l
+                    for _ in range(iters[LEVELS - 1 - l]):
+                        sums, _ = ctx.icp_accumulate(np.float32(R).reshape(-1), np.float32(t), intr, l, 0.1,
+                                                     math.radians(30.0), cur_p[l].data_ptr(), c_ * 16, cur_n[l].data_ptr(),
+                                                     c_ * 16, prv_p[l].data_ptr(), c_ * 16, prv_n[l].data_ptr(), c_ * 16,
+                                                     r_, c_)
+                        A, b, k = np.zeros((6, 6)), np.zeros(6), 0
+                        for i in range(6):
+                            for j in range(i, 7):
+                                if j == 6:
+                                    b[i] = sums[k]
+                                else:
+                                    A[i, j] = A[j, i] = sums[k]
+                                k += 1
+                        x = np.linalg.solve(A, b)
+                        Ri = rodrigues(x[:3])
+                        R, t = Ri @ R, Ri @ t + x[3:]
+            else:
+                lv = [(cur_p[l].data_ptr(), cur_n[l].data_ptr(), prv_p[l].data_ptr(), prv_n[l].data_ptr(), (cols >> l) * 16,
+                       rows >> l, cols >> l, iters[::-1][l]) for l in range(LEVELS)]
+                Rl, tl, ok = ctx.icp_estimate(np.eye(3).reshape(-1), np.zeros(3), intr, 0.1, math.radians(30.0), lv)
+                assert ok
+                R, t = np.array(Rl, dtype=np.float64).reshape(3, 3), np.array(tl, dtype=np.float64)
             pose_R, pose_t = pose_R @ R, pose_R @ t + pose_t
         elif f > 0:
             pose_R, pose_t = c2v(frames[f][1], frames[f][2])
@@ -120,7 +129,7 @@ def main():
         worst = max(worst, float(np.linalg.norm(pose_t - tt)))
     wall = time.perf_counter() - t_start
     print("%d^3, %d frames of the S2 orbit, ICP %s: %.1f frames/s (wall %.3f s); worst position error %.1f mm" % (
-        n, args.frames, "off (true poses)" if args.no_icp else "on", args.frames / wall, wall, worst * 1e3))
+        n, args.frames, "off (true poses)" if args.no_icp else ("on (host loop)" if args.host_icp else "on (device loop)"), args.frames / wall, wall, worst * 1e3))
     print("per frame, stream time between events [ms]: " + ", ".join("%s %.3f" % (k, v / args.frames) for k, v in stage.items()))
     ctx.close()
 

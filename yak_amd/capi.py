@@ -19,7 +19,7 @@ EXPORTS = [
     "yakhip_clear_volume", "yakhip_compute_dists", "yakhip_integrate", "yakhip_integrate_batch",
     "yakhip_raycast_points", "yakhip_raycast_depth",
     "yakhip_bilateral_filter", "yakhip_truncate_depth", "yakhip_depth_pyramid", "yakhip_compute_points_normals",
-    "yakhip_resize_points_normals", "yakhip_icp_accumulate", "yakhip_marching_cubes",
+    "yakhip_resize_points_normals", "yakhip_icp_accumulate", "yakhip_icp_estimate", "yakhip_marching_cubes",
 ]
 
 
@@ -52,6 +52,15 @@ class FrameDesc(C.Structure):
         ("R", C.c_float * 9),
         ("t", C.c_float * 3),
         ("intr", C.c_float * 4),
+    ]
+
+
+class IcpLevel(C.Structure):
+    """struct yakhip_icp_level"""
+    _fields_ = [
+        ("vcurr", C.c_void_p), ("ncurr", C.c_void_p), ("vprev", C.c_void_p), ("nprev", C.c_void_p),
+        ("vcurr_pitch", C.c_size_t), ("ncurr_pitch", C.c_size_t), ("vprev_pitch", C.c_size_t), ("nprev_pitch", C.c_size_t),
+        ("rows", C.c_int), ("cols", C.c_int), ("iterations", C.c_int),
     ]
 
 
@@ -99,6 +108,7 @@ def load():
         "yakhip_depth_pyramid": [vp, vp, sz, i, i, vp, sz, C.c_float],
         "yakhip_compute_points_normals": [vp, fp, vp, sz, i, i, vp, sz, vp, sz],
         "yakhip_resize_points_normals": [vp, vp, sz, vp, sz, i, i, vp, sz, vp, sz],
+        "yakhip_icp_estimate": [vp, fp, fp, fp, C.c_float, C.c_float, C.POINTER(IcpLevel), i, fp, fp, C.POINTER(i)],
         "yakhip_marching_cubes": [vp, volp, i, C.c_double, vp, C.c_ulonglong, C.POINTER(C.c_ulonglong)],
         "yakhip_icp_accumulate": [vp, fp, fp, fp, i, C.c_float, C.c_float, vp, sz, vp, sz, vp, sz, vp, sz, i, i, fp,
                                   C.POINTER(i)],
@@ -244,6 +254,19 @@ class Context:
                                           ncurr_pitch, C.c_void_p(vprev_ptr), vprev_pitch, C.c_void_p(nprev_ptr),
                                           nprev_pitch, rows, cols, sums, counts))
         return list(sums), list(counts)
+
+    def icp_estimate(self, R, t, intr, dist_thres, angle_thres, levels):
+        """levels: per pyramid level l = 0.. a tuple (vcurr_ptr, ncurr_ptr, vprev_ptr, nprev_ptr, pitch, rows, cols,
+        iterations).  Blocking.  Returns (R 3x3 list, t list, ok)."""
+        arr = (IcpLevel * len(levels))()
+        for d, (vc, nc, vp_, np_, pitch, rows, cols, iters) in zip(arr, levels):
+            d.vcurr, d.ncurr, d.vprev, d.nprev = vc, nc, vp_, np_
+            d.vcurr_pitch = d.ncurr_pitch = d.vprev_pitch = d.nprev_pitch = pitch
+            d.rows, d.cols, d.iterations = rows, cols, iters
+        Ro, to, ok = (C.c_float * 9)(), (C.c_float * 3)(), C.c_int(0)
+        _chk(load().yakhip_icp_estimate(self._h, _f32(R, 9), _f32(t, 3), _f32(intr, 4), dist_thres, angle_thres, arr,
+                                        len(levels), Ro, to, C.byref(ok)))
+        return list(Ro), list(to), bool(ok.value)
 
     def marching_cubes(self, vol, min_weight, scale, triangles_ptr=0, capacity=0):
         """Blocking.  Returns the number of triangles the slab produces (written iff it fits `capacity`)."""

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include "solve6.hpp"
 #include "yakhip_internal.h"
 
 namespace yakhip
@@ -688,6 +689,99 @@ int yakhip_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], c
   return launch_icp_accumulate(ctx, R, t, intr, level, dist_thres, angle_thres, (const uint8_t*)vcurr_dev, vcurr_pitch,
                                (const uint8_t*)ncurr_dev, ncurr_pitch, (const uint8_t*)vprev_dev, vprev_pitch,
                                (const uint8_t*)nprev_dev, nprev_pitch, rows, cols, sums_host, counts_host);
+}
+
+int yakhip_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], float dist_thres,
+                        float angle_thres, const yakhip_icp_level* levels, int n_levels, float R_out[9], float t_out[3],
+                        int* ok)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!R || !t || !intr || !levels || !R_out || !t_out || !ok)
+    return fail(YAKHIP_EINVAL, "icp_estimate: null argument");
+  if (n_levels < 1 || n_levels > 16)
+    return fail(YAKHIP_EINVAL, "icp_estimate: %d pyramid levels outside [1, 16]", n_levels);
+  for (int l = 0; l < n_levels; ++l)
+  {
+    const yakhip_icp_level& L = levels[l];
+    if (L.iterations < 0)
+      return fail(YAKHIP_EINVAL, "icp_estimate: negative iteration count on level %d", l);
+    if ((rc = check_image("icp_estimate(vcurr)", L.vcurr, L.vcurr_pitch, L.rows, L.cols, 16)) != 0 ||
+        (rc = check_image("icp_estimate(ncurr)", L.ncurr, L.ncurr_pitch, L.rows, L.cols, 16)) != 0 ||
+        (rc = check_image("icp_estimate(vprev)", L.vprev, L.vprev_pitch, L.rows, L.cols, 16)) != 0 ||
+        (rc = check_image("icp_estimate(nprev)", L.nprev, L.nprev_pitch, L.rows, L.cols, 16)) != 0)
+      return rc;
+  }
+  *ok = 1;
+  int status = 0, iterations = 0;
+  if ((rc = launch_icp_estimate(ctx, R, t, intr, dist_thres, angle_thres, levels, n_levels, R_out, t_out, &status,
+                                &iterations)) != 0)
+    return rc;
+  if (status == 0)
+    return 0;
+
+  // Slow path, the reference's own control flow (projective_icp.cpp:195-231): one blocking accumulation
+  // per linearisation, determinant test, SVD solve and composition on the host.
+  float Rc[9], tc[3];
+  memcpy(Rc, R, sizeof(Rc));
+  memcpy(tc, t, sizeof(tc));
+  for (int l = n_levels - 1; l >= 0; --l)
+  {
+    const yakhip_icp_level& L = levels[l];
+    for (int it = 0; it < L.iterations; ++it)
+    {
+      float sums[27];
+      if ((rc = launch_icp_accumulate(ctx, Rc, tc, intr, l, dist_thres, angle_thres, (const uint8_t*)L.vcurr,
+                                      L.vcurr_pitch, (const uint8_t*)L.ncurr, L.ncurr_pitch, (const uint8_t*)L.vprev,
+                                      L.vprev_pitch, (const uint8_t*)L.nprev, L.nprev_pitch, L.rows, L.cols, sums,
+                                      nullptr)) != 0)
+        return rc;
+      double A[36], b[6], r[6];
+      int shift = 0;
+      for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 7; ++j)
+        {
+          const double value = sums[shift++];
+          if (j == 6)
+            b[i] = value;
+          else
+            A[j * 6 + i] = A[i * 6 + j] = value;
+        }
+      const double det = yak::host::det6(A);
+      if (fabs(det) < 1e-15 || det != det)
+      {
+        *ok = 0;
+        memcpy(R_out, Rc, sizeof(Rc));
+        memcpy(t_out, tc, sizeof(tc));
+        return 0;
+      }
+      yak::host::solve6_svd_symmetric(A, b, r);
+      // Affine3f(rvec, t) and Tinc * corrected, in the arithmetic of include/yak/kfusion/compat/linalg.hpp
+      const float rv[3] = { (float)r[0], (float)r[1], (float)r[2] };
+      float Ri[9] = { 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f };
+      const double th = sqrt((double)rv[0] * rv[0] + (double)rv[1] * rv[1] + (double)rv[2] * rv[2]);
+      if (th > 2.220446049250313e-16)
+      {
+        const double kx = rv[0] / th, ky = rv[1] / th, kz = rv[2] / th, c = cos(th), s = sin(th), v = 1.0 - c;
+        Ri[0] = (float)(c + kx * kx * v), Ri[1] = (float)(kx * ky * v - kz * s), Ri[2] = (float)(kx * kz * v + ky * s);
+        Ri[3] = (float)(ky * kx * v + kz * s), Ri[4] = (float)(c + ky * ky * v), Ri[5] = (float)(ky * kz * v - kx * s);
+        Ri[6] = (float)(kz * kx * v - ky * s), Ri[7] = (float)(kz * ky * v + kx * s), Ri[8] = (float)(c + kz * kz * v);
+      }
+      float Rn[9], tn[3];
+      for (int rr = 0; rr < 3; ++rr)
+      {
+        for (int cc = 0; cc < 3; ++cc)
+          Rn[3 * rr + cc] = Ri[3 * rr + 0] * Rc[0 + cc] + Ri[3 * rr + 1] * Rc[3 + cc] + Ri[3 * rr + 2] * Rc[6 + cc];
+        tn[rr] = (Ri[3 * rr + 0] * tc[0] + Ri[3 * rr + 1] * tc[1] + Ri[3 * rr + 2] * tc[2]) + (float)r[3 + rr];
+      }
+      memcpy(Rc, Rn, sizeof(Rc));
+      memcpy(tc, tn, sizeof(tc));
+    }
+  }
+  memcpy(R_out, Rc, sizeof(Rc));
+  memcpy(t_out, tc, sizeof(tc));
+  return 0;
 }
 
 // ---- surface extraction ------------------------------------------------------------------------

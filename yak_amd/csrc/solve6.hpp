@@ -1,6 +1,7 @@
 // solve6.hpp -- the two pieces of dense linear algebra ProjectiveICP asks OpenCV for, restated without
 // it: cv::determinant of the 6 x 6 normal matrix and cv::solve(A, b, x, DECOMP_SVD)
-// (reference yak/src/kfusion/projective_icp.cpp:215, 225).  Internal to the host layer.
+// (reference yak/src/kfusion/projective_icp.cpp:215, 225).  Shared by the C++ host layer
+// (ProjectiveICP::estimateTransform) and by the slow path of yakhip_icp_estimate; not installed.
 //
 // OpenCV is un-vendored and unpinned in the reference (CMakeLists.txt:16), so this is "parity
 // unpinned" by construction: same mathematics (LU determinant; minimum-norm least squares through the

@@ -133,6 +133,11 @@ int launch_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], c
 int launch_marching_cubes(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int z0, int layers, int min_weight,
                           double scale, float* triangles, unsigned long long capacity, unsigned long long* n_out);
 
+// icp.hip: the device-resident schedule.  status_out: 0 = done, 2 = some system needs the host path.
+int launch_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], float dist_thres,
+                        float angle_thres, const yakhip_icp_level* levels, int n_levels, float R_out[9], float t_out[3],
+                        int* status_out, int* iterations_out);
+
 // ---- device helpers shared by kernels --------------------------------------------------------
 __device__ __forceinline__ float half_bits_to_float(uint32_t bits)
 {

@@ -7,7 +7,6 @@
 #include <iostream>
 #include <stdexcept>
 
-#include "solve6.hpp"
 
 namespace kfusion
 {
@@ -46,9 +45,9 @@ int ProjectiveICP::getUsedLevelsNum() const
   return i + 1;
 }
 
-// :175-232.  Coarse to fine; per iteration one device pass gives the 27 sums of the normal
-// equations (blocking), the 6 x 6 system is solved on the host and the increment is composed on the
-// left of the running estimate.
+// :175-232.  Coarse to fine.  The reference comes back to the host after every linearisation (stream
+// sync, cv::determinant, cv::solve, compose); yakhip_icp_estimate chains accumulation, reduction, solve
+// and pose update on the device and is waited for once (include/yakhip.h).
 bool ProjectiveICP::estimateTransform(const Affine3f& affine, Affine3f& correctedAffine, const Intr& intr,
                                       const PointsPyr& vcurr, const NormalsPyr ncurr, const PointsPyr vprev,
                                       const NormalsPyr nprev)
@@ -57,55 +56,34 @@ bool ProjectiveICP::estimateTransform(const Affine3f& affine, Affine3f& correcte
   if ((int)vcurr.size() < LEVELS || (int)ncurr.size() < LEVELS || (int)vprev.size() < LEVELS || (int)nprev.size() < LEVELS)
     throw std::invalid_argument("ProjectiveICP::estimateTransform: pyramids shorter than the used levels");
   correctedAffine = affine;
-  const float in[4] = { intr.fx, intr.fy, intr.cx, intr.cy };
+  if (LEVELS == 0)
+    return true;
 
-  for (int level_index = LEVELS - 1; level_index >= 0; --level_index)
+  std::vector<yakhip_icp_level> levels((size_t)LEVELS);
+  for (int l = 0; l < LEVELS; ++l)
   {
-    const Normals& n = nprev[level_index];
-    const Cloud& v = vprev[level_index];
-    const Cloud& vc = vcurr[level_index];
-    const Normals& nc = ncurr[level_index];
-
-    for (int iter = 0; iter < iters_[level_index]; ++iter)
-    {
-      const Mat3f R = correctedAffine.rotation();
-      const Vec3f t = correctedAffine.translation();
-      const float tf[3] = { t[0], t[1], t[2] };
-      float sums[27];
-      if (yakhip_icp_accumulate(context(), R.val, tf, in, level_index, dist_thres_, angle_thres_, vc.ptr(), vc.step(),
-                                nc.ptr(), nc.step(), v.ptr(), v.step(), n.ptr(), n.step(), n.rows(), n.cols(), sums,
-                                nullptr) != 0)
-        error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_icp_accumulate");
-
-      // StreamHelper::get, :42-61 (A is float in the reference; the values are widened unchanged)
-      double A[36], b[6];
-      int shift = 0;
-      for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 7; ++j)
-        {
-          const double value = sums[shift++];
-          if (j == 6)
-            b[i] = value;
-          else
-            A[j * 6 + i] = A[i * 6 + j] = value;
-        }
-
-      // :214-222 checking nullspace
-      const double det = yak::host::det6(A);
-      if (std::fabs(det) < 1e-15 || std::isnan(det))
-      {
-        if (std::isnan(det))
-          std::cout << "qnan" << std::endl;
-        return false;
-      }
-
-      double r[6];
-      yak::host::solve6_svd_symmetric(A, b, r);  // :224-225
-      const Affine3f Tinc(Vec3f((float)r[0], (float)r[1], (float)r[2]), Vec3f((float)r[3], (float)r[4], (float)r[5]));
-      correctedAffine = Tinc * correctedAffine;  // :227-228
-    }
+    yakhip_icp_level& L = levels[(size_t)l];
+    L.vcurr = vcurr[l].ptr(), L.vcurr_pitch = vcurr[l].step();
+    L.ncurr = ncurr[l].ptr(), L.ncurr_pitch = ncurr[l].step();
+    L.vprev = vprev[l].ptr(), L.vprev_pitch = vprev[l].step();
+    L.nprev = nprev[l].ptr(), L.nprev_pitch = nprev[l].step();
+    L.rows = nprev[l].rows(), L.cols = nprev[l].cols();  // :200-201
+    L.iterations = iters_[l];
   }
-  return true;
+  const Mat3f R = affine.rotation();
+  const Vec3f t = affine.translation();
+  const float tf[3] = { t[0], t[1], t[2] }, in[4] = { intr.fx, intr.fy, intr.cx, intr.cy };
+  float Ro[9], to[3];
+  int ok = 0;
+  if (yakhip_icp_estimate(context(), R.val, tf, in, dist_thres_, angle_thres_, levels.data(), LEVELS, Ro, to, &ok) != 0)
+    error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_icp_estimate");
+  Mat3f Rm;
+  for (int i = 0; i < 9; ++i)
+    Rm.val[i] = Ro[i];
+  correctedAffine = Affine3f(Rm, Vec3f(to[0], to[1], to[2]));
+  if (!ok)
+    std::cout << "ICP: singular normal equations" << std::endl;  // :217-222
+  return ok != 0;
 }
 }  // namespace cuda
 }  // namespace kfusion
