@@ -178,7 +178,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--scene", default="s0", choices=["s0", "s1"], help="s1 = sphere+wall (partial updates); N=1 only")
+    ap.add_argument("--scene", default="s0", choices=["s0", "s1", "s2"],
+                    help="s1 = sphere+wall, s2 = a view of the orbit scene (partial updates); N=1 only")
     ap.add_argument("--z-chunk", type=int, default=0)
     ap.add_argument("--vx", type=int, default=0, help="cap on voxels per lane (tuning)")
     ap.add_argument("--tile", type=int, default=0, help="wave footprint: log2 lanes along x, 3..6 (tuning)")
@@ -218,7 +219,9 @@ def main():
     z0, z1 = slab_range(dims[2], world, rank)
     slab_voxels = dims[0] * dims[1] * (z1 - z0)
 
-    if args.scene == "s1" and world == 1:
+    if args.scene == "s2" and world == 1:
+        depth, R, t = synth.scene_s2(40)
+    elif args.scene == "s1" and world == 1:
         depth, R, t = synth.scene_s1()
     else:
         depth, R, t = wall_scene(dims, voxel)
@@ -302,7 +305,7 @@ def main():
         workload = "%dx%dx%d volume (%d^3 voxels per GPU, z-slabs), one %dx%d synthetic depth frame per step, " \
                    "scene %s, integrate only" % (dims[0], dims[1], dims[2], VOXELS_PER_RANK_EDGE, cols, rows,
                                                  "S0 wall (every voxel updates)" if args.scene == "s0" or world > 1
-                                                 else "S1 sphere+wall")
+                                                 else {"s1": "S1 sphere+wall", "s2": "S2 orbit view 40"}[args.scene])
         out = {
             "metric": "voxel updates/sec",
             "value": round(gvox, 3),

@@ -198,8 +198,14 @@ __global__ __launch_bounds__(256) void prepass_kernel(const uint8_t* dists, uint
     const int y = (int)(blockIdx.x / thr_blocks_x);
     if (x >= cols)
       return;
-    const float Dp = half_bits_to_float(*(const uint16_t*)(dists + (size_t)y * dists_pitch + (size_t)x * 2u));
-    thr[(size_t)y * cols + x] = band_thresholds(Dp, trunc_hi);
+    const uint32_t bits = *(const uint16_t*)(dists + (size_t)y * dists_pitch + (size_t)x * 2u);
+    f32x2 ab = band_thresholds(half_bits_to_float(bits), trunc_hi);
+    // second word: B2 rounded UP to its upper 16 bits (still a sufficient "behind" threshold, 2^-8 looser)
+    // with the pixel's half ray length in the lower 16 -- read as a float it is >= that rounded B2, so
+    // the kernel compares d2 against the word as it is, and the band path finds Dp without a second gather
+    if (ab.y >= 0.f)
+      ab.y = __uint_as_float(((__float_as_uint(ab.y) + 0xffffu) & 0xffff0000u) | bits);
+    thr[(size_t)y * cols + x] = ab;
     return;
   }
   const int cell = (int)(blockIdx.x - thr_blocks) * 4 + (int)(threadIdx.x >> 6);
@@ -425,27 +431,47 @@ __device__ __forceinline__ void settle(const IntegrateParams& p, const Pos<VX>& 
     }
     if (rare_any != 0)  // wave-uniform branch
     {
-      // Masks are wave-wide values: they may only be updated in wave-uniform control flow.  Inside
-      // the per-lane regions below only per-lane variables change; the ballots come after the join.
-      bool exact_hit[VX];
+      // Inside the truncation band the reference's expression is evaluated as written (tsdf_volume.cu:92-96)
+      // on what stage 1 already holds: d2 = dot(vc, vc) bit for bit, and the pixel's ray length in the low
+      // half of the threshold word.  Straight-line for all VX voxels; the masks pick the lanes it is for.
+      mask_t slow_any = 0;
 #pragma unroll
       for (int v = 0; v < VX; ++v)
       {
-        exact_hit[v] = false;
-        if (lanes(rare[v]))
-        {
-          float t = 1.f;
-          exact_hit[v] = measure_exact(p, c.x[Pos<VX>::pair_of(v)][Pos<VX>::half_of(v)],
-                                       c.y[Pos<VX>::pair_of(v)][Pos<VX>::half_of(v)],
-                                       c.z[Pos<VX>::pair_of(v)][Pos<VX>::half_of(v)], t);
-          tsdf[v] = t;
-        }
+        const mask_t band = rare[v] & ~pr.slow[v];
+        const float Dp = half_bits_to_float(__float_as_uint(pr.ab[v].y) & 0xffffu);
+        const float sdf = Dp - __builtin_sqrtf(pr.d2[v]);
+        const float t = __builtin_fminf(1.f, sdf * p.trunc_inv);
+        const mask_t in_band = band & ballot(sdf >= -p.trunc);
+        tsdf[v] = lanes(in_band) ? t : tsdf[v];
+        hit[v] |= in_band;
+        unit[v] |= in_band & ballot(t == 1.f);
+        slow_any |= rare[v] & pr.slow[v];
       }
-#pragma unroll
-      for (int v = 0; v < VX; ++v)
+      if (slow_any != 0)  // wave-uniform: vc.z outside the Markstein range, practically never
       {
-        hit[v] |= ballot(exact_hit[v]);
-        unit[v] |= ballot(exact_hit[v] && tsdf[v] == 1.f);
+        // Masks are wave-wide values: they may only be updated in wave-uniform control flow.  Inside
+        // the per-lane regions below only per-lane variables change; the ballots come after the join.
+        bool exact_hit[VX];
+#pragma unroll
+        for (int v = 0; v < VX; ++v)
+        {
+          exact_hit[v] = false;
+          if (lanes(rare[v] & pr.slow[v]))
+          {
+            float t = 1.f;
+            exact_hit[v] = measure_exact(p, c.x[Pos<VX>::pair_of(v)][Pos<VX>::half_of(v)],
+                                         c.y[Pos<VX>::pair_of(v)][Pos<VX>::half_of(v)],
+                                         c.z[Pos<VX>::pair_of(v)][Pos<VX>::half_of(v)], t);
+            tsdf[v] = exact_hit[v] ? t : tsdf[v];
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < VX; ++v)
+        {
+          hit[v] |= ballot(exact_hit[v]);
+          unit[v] |= ballot(exact_hit[v] && tsdf[v] == 1.f);
+        }
       }
     }
   }
