@@ -124,6 +124,7 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->zu = 0;
   ctx->group_test = 1;
   ctx->tile_shift = 0;
+  ctx->mc_z_chunk = 0;
   ctx->thr = nullptr;
   ctx->thr_bytes = 0;
   ctx->icp_scratch = nullptr;
@@ -239,6 +240,13 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
     if (value != 0 && (value < 3 || value > 6))
       return fail(YAKHIP_EINVAL, "tile must be 0 (default) or 3..6");
     ctx->tile_shift = value;
+    return 0;
+  }
+  if (strcmp(key, "mc_z_chunk") == 0)
+  {
+    if (value < 0)
+      return fail(YAKHIP_EINVAL, "mc_z_chunk must be >= 0");
+    ctx->mc_z_chunk = value;
     return 0;
   }
   if (strcmp(key, "zu") == 0)

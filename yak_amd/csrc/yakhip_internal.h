@@ -20,6 +20,7 @@ struct yakhip_ctx
   int zu;              // (unused; kept for option compatibility)
   int group_test;      // coarse group test on (default) / off
   int tile_shift;      // 0 = default wave footprint, else 3..6 (tuning)
+  int mc_z_chunk;      // 0 = default cube layers per marching-cubes tile (tuning)
   void* thr;           // scratch: per-pixel band thresholds of the frame being integrated
   size_t thr_bytes;
   void* icp_scratch;   // ICP: workgroup partials + the reduced 33 values (device)
