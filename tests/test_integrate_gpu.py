@@ -352,3 +352,44 @@ def test_integrate_group_test_switch_does_not_change_results(gpu_ctx):
     for _ in range(2):
         oracle.integrate(want, dims, vs, tr, 64, dists, R, t, synth.INTR, nthreads=oracle.max_threads())
     assert_parity(a, want)
+
+
+@pytest.mark.parametrize("n,z0,z1,tile", [(1024, 500, 532, 0), (2048, 100, 108, 0), (1024, 37, 61, 4)])
+def test_integrate_slab_of_a_large_volume(gpu_ctx, n, z0, z1, tile):
+    """Configs C4 / C5 by their index ranges: a slab of a 1024^3 / 2048^3 volume (the whole
+    volumes are 4 and 32 GiB) -- 16-MiB layers, starts deep inside the volume (hundreds of replayed z
+    steps), 64-bit slab addressing -- word for word against the oracle's same slab."""
+    dims, vs, tr = synth.volume_geometry(n)
+    depth, R, t = synth.scene_s2(200)
+    dists = oracle.compute_dists(depth, synth.INTR)
+    start = np.zeros(n * n * (z1 - z0), dtype=np.uint32)
+    want = start.copy()
+    _, updated = oracle.integrate(want, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR, z0=z0, z1=z1, nthreads=16)
+    assert updated > 100000
+    gpu_ctx.set_option("tile", tile)
+    try:
+        got = gpu_integrate(gpu_ctx, start, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR, z0=z0, z1=z1)
+    finally:
+        gpu_ctx.set_option("tile", 0)
+    assert np.array_equal(got >> 16, want >> 16) and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("tile", [3, 4, 5, 6])
+def test_integrate_wave_footprint_does_not_change_results(gpu_ctx, tile):
+    # "tile" folds a wave into 2^tile lanes along x by 64 >> tile rows; volumes it does not divide
+    # (the second case) quietly use the next footprint that fits
+    for n in ((128, 64, 40), (96, 48, 24)):
+        dims, vs, tr = synth.volume_geometry(n)
+        depth, R, t = synth.scene_s2(77)
+        dists = oracle.compute_dists(depth, synth.INTR)
+        want = np.zeros(int(np.prod(dims)), dtype=np.uint32)
+        for _ in range(2):
+            oracle.integrate(want, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR, nthreads=8)
+        gpu_ctx.set_option("tile", tile)
+        try:
+            got = gpu_integrate(gpu_ctx, np.zeros_like(want), dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR, frames=2)
+        finally:
+            gpu_ctx.set_option("tile", 0)
+        assert np.array_equal(got, want)
+    with pytest.raises(capi.YakHipError):
+        gpu_ctx.set_option("tile", 2)
