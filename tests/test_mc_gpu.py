@@ -101,6 +101,41 @@ def test_mc_capacity_and_degenerate_volumes(gpu_ctx):
         gpu_ctx.marching_cubes(desc, 4, 1.0, buf.data_ptr() + 2, n)           # misaligned output
 
 
+def noise_volume(dims, seed):
+    """Every cube its own case: random tsdf halves in [-1, 1] (signed zeros among them), weights 0..3."""
+    rng = np.random.default_rng(seed)
+    n = int(np.prod(dims))
+    tsdf = rng.uniform(-1, 1, n).astype(np.float16)
+    tsdf[rng.random(n) < 0.05] = np.float16(0.0)
+    tsdf[rng.random(n) < 0.05] = np.float16(-0.0)
+    weight = rng.integers(0, 4, n).astype(np.uint32)
+    return tsdf.view(np.uint16).astype(np.uint32) | (weight << 16)
+
+
+@pytest.mark.parametrize("dims,min_weight", [((70, 19, 21), 0), ((64, 8, 40), 1), ((130, 33, 18), 1), ((5, 5, 70), 1)])
+def test_mc_noise_every_case_and_full_cube_queues(gpu_ctx, dims, min_weight):
+    """Dense random surface: up to 5 triangles in every cube, so the emit pass's cube queue fills and
+    drains many times per tile, on volumes whose edges cut the 63 x 4 wave tiles."""
+    vol = noise_volume(dims, sum(dims))
+    want = oracle.marching_cubes(vol, dims, min_weight, 0.37)
+    got = gpu_mc(gpu_ctx, torch.from_numpy(vol.view(np.int32)).cuda(), dims, min_weight, 0.37)
+    assert len(got) == len(want) > 50
+    assert np.array_equal(canon(got), canon(want))
+
+
+@pytest.mark.parametrize("depth", [1, 3, 5, 16, 64])
+def test_mc_tile_depth_option_does_not_change_the_set(gpu_ctx, depth):
+    vol = noise_volume((66, 9, 37), 11)
+    vol[: 66 * 9 * 12] = 0x00013C00                                        # free space below: empty tiles
+    want = canon(oracle.marching_cubes(vol, (66, 9, 37), 1))
+    gpu_ctx.set_option("mc_z_chunk", depth)
+    try:
+        got = gpu_mc(gpu_ctx, torch.from_numpy(vol.view(np.int32)).cuda(), (66, 9, 37), 1)
+    finally:
+        gpu_ctx.set_option("mc_z_chunk", 0)
+    assert np.array_equal(canon(got), want)
+
+
 def test_mc_512_volume_fused_on_gpu(gpu_ctx):
     n = 512
     dims, vs, tr = synth.volume_geometry(n)

@@ -6,17 +6,22 @@
 // (the reference's own output order is nondeterministic: OpenMP + a critical section, :163-171).
 // Schedule: classify+count -> exclusive scan -> classify+emit, both volume passes streaming:
 //   * a wave owns a tile of 63 cubes along x (64 voxels: lane i holds the voxels at x0 + i, the cube
-//     corners at x + 1 come from lane i + 1 by a cross-lane move, no second load) times 4 cube rows
-//     (5 voxel rows: 1.25 dword loads per cube and layer, each a 256-byte row segment), and walks a
-//     chunk of z layers keeping the previous layer in registers;
-//   * the four waves of a workgroup stack their tiles in y, so of the 17 voxel rows a workgroup needs
-//     only one is shared with the next workgroup (1.06x the volume from the fabric; a wave per row
-//     pair measured 1.77x);
-//   * the output position of every triangle is fixed by the scan (tile order, then z, row, x, then the
-//     case table's order): the result is deterministic, no atomics.  The emit pass is latency-bound
-//     (few waves hold surface, each walks its cubes serially), so lanes store their triangles
-//     directly: staging a step's triangles in LDS for full-row stores measured slower.
+//     corners at x + 1 come from lane i + 1) times 4 cube rows (5 voxel rows: 1.25 dword loads per cube
+//     and layer, each a 256-byte row segment), and walks a chunk of z layers keeping the previous layer
+//     in registers and the next one in flight;
+//   * the four waves of a workgroup stack their tiles in y, and in the count pass every XCD gets a
+//     contiguous run of workgroups, so that the 128-byte lines and voxel rows that neighbouring tiles
+//     share meet in one L2: 1.12x the volume from the fabric (FETCH_SIZE; round-robin workgroups 1.66x);
+//   * classification is done on wave masks and starts with the question "is any voxel of these two
+//     layers negative": free and unseen space, most of the volume, costs five compares a layer.  The
+//     count pass is bound by memory (0.11 ms for 512 MiB; a plain streaming read takes 0.08);
+//   * the output position of every triangle is fixed by the scan (tile order, then the order in which the
+//     tile's cubes are queued: z, row, x, then the case table's order): deterministic, no atomics;
+//   * the emit pass takes the tiles that hold triangles, queues their surface cubes in LDS and works
+//     them off 64 at a time, a cube per lane and a triangle per step, whatever rows and layers the
+//     cubes came from (row by row a curved surface kept 4 of 64 lanes busy: 0.19 ms against 0.09).
 #include "yakhip_internal.h"
+#include <algorithm>
 
 #define YAK_MC_TABLE_DECL __constant__ const
 #include "mc_case_table.h"
@@ -65,15 +70,36 @@ template <bool EMIT>
 __global__ __launch_bounds__(256) void mc_kernel(const McParams p, uint32_t* counts, const uint32_t* local_offsets,
                                                  const unsigned long long* block_bases, float* triangles)
 {
-  __shared__ uint64_t table[256];
-  __shared__ float vals[EMIT ? 4 : 1][8][64];
-  table[threadIdx.x] = yak_mc_case_table[threadIdx.x];
-  __syncthreads();
+  // The case table in LDS.  The emit pass keeps a copy per wave and fills it only after the wave knows that
+  // its tile holds triangles: nearly all of its waves leave at once, and a workgroup barrier behind a
+  // table load would keep each of them resident for two memory round trips.
+  __shared__ uint64_t table_lds[EMIT ? 4 : 1][256];
+  // emit pass: per wave, a ring of cubes that hold triangles, field-major (4 words of corner halves, the
+  // case entry, the cube's place in the tile)
+  __shared__ uint32_t queue[EMIT ? 4 : 1][7][EMIT ? 128 : 1];
+  if (!EMIT)
+  {
+    table_lds[0][threadIdx.x] = yak_mc_case_table[threadIdx.x];
+    __syncthreads();
+  }
 
-  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+  // (the wave index through readfirstlane: the compiler cannot see that it is uniform over the wave, and
+  // everything derived from it -- the tile, the row tests, the surface masks -- should live in scalars)
+  const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   // the count pass walks z_chunk layers and closes a tile every z_sub layers; the emit pass takes one
   // tile per wave, so that the few waves that hold surface are short and many
-  const int xt = (int)blockIdx.x, yt = (int)blockIdx.y * 4 + wave, zc = (int)blockIdx.z;
+  // Workgroups go to the 8 XCDs round-robin and each XCD has its own L2.  A 63-cube tile row is 256
+  // bytes at a 252-byte pitch, so x-neighbours share a 128-byte line (and y-neighbours a voxel row):
+  // with neighbours on different XCDs the count pass fetched 1.66x the volume (FETCH_SIZE).  Give each
+  // XCD a contiguous run of tiles instead, x fastest, so that the shared lines meet in one L2.
+  const unsigned n_wg = gridDim.x, per_xcd = n_wg / 8u;
+  // (count pass only: the emit pass's work sits in the few tiles that hold surface, and round-robin
+  // spreads those over the XCDs; contiguous runs measured 0.31 ms against 0.21)
+  const unsigned wg =
+      !EMIT && blockIdx.x < per_xcd * 8u ? (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u : blockIdx.x;
+  const unsigned gy = (unsigned)(p.ny + 3) / 4u;
+  const int xt = (int)(wg % (unsigned)p.nx), yt = (int)((wg / (unsigned)p.nx) % gy) * 4 + wave,
+            zc = (int)(wg / ((unsigned)p.nx * gy));
   if (yt >= p.ny)
     return;
   const int walk = EMIT ? p.z_sub : p.z_chunk;
@@ -85,7 +111,12 @@ __global__ __launch_bounds__(256) void mc_kernel(const McParams p, uint32_t* cou
     if (counts[tile] == 0)
       return;
     out = block_bases[tile / kScanBlock] + local_offsets[tile];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      table_lds[wave][lane + 64 * i] = yak_mc_case_table[lane + 64 * i];
+    // (read back by this wave only: LDS operations of one wave complete in order)
   }
+  const uint64_t* table = table_lds[EMIT ? wave : 0];
 
   const int x = xt * kRun + lane;
   const int y0 = yt * kRows;
@@ -94,100 +125,204 @@ __global__ __launch_bounds__(256) void mc_kernel(const McParams p, uint32_t* cou
   const size_t plane = (size_t)p.X * p.Y;
   const int zl0 = zc * walk, zl1 = min(zl0 + walk, p.cube_layers);  // local cube layers
 
-  // voxel rows y0 .. y0 + 4 (clamped to the volume: a clamped row only feeds cube rows that do not exist)
-  const uint32_t* rowp[kRows + 1];
+  // voxel rows y0 .. y0 + 4 (clamped to the volume: a clamped row only feeds cube rows that do not exist),
+  // as dword offsets within a layer; the layer base is a scalar
+  uint32_t row_off[kRows + 1];
 #pragma unroll
   for (int r = 0; r <= kRows; ++r)
-    rowp[r] = p.vol + (size_t)min(y0 + r, p.Y - 1) * p.X + (in_x ? x : 0);
+    row_off[r] = (uint32_t)min(y0 + r, p.Y - 1) * (uint32_t)p.X + (uint32_t)(in_x ? x : 0);  // past the row: voxel 0
 
-  uint32_t w_lo[kRows + 1], n_lo[kRows + 1];  // layer z: own word, the word at x + 1
+  // Classification runs on wave masks (one bit per lane, scalar registers).  The CU's scalar unit issues
+  // no faster than a SIMD's vector unit, so masks are not free either, and most of the volume is free or
+  // unseen space: a tile layer costs five compares (which voxels are negative) and a few scalar
+  // operations unless one of its two voxel layers holds a negative voxel.  Only then are the masks
+  // combined per cube (all 8 corners valid and of mixed sign: cases 0 and 255 and invalid cubes have no
+  // triangle), and only the cube rows that hold surface go on to the per-lane case lookup.
+  const uint64_t cube_lanes = __builtin_amdgcn_ballot_w64(has_cube);
+  const uint64_t voxel_lanes = __builtin_amdgcn_ballot_w64(in_x);
+  // weight test of voxel_code as one unsigned compare of the whole word
+  const uint32_t weight_thr = p.min_weight <= 0 ? 0u : (uint32_t)p.min_weight << 16;
+  uint64_t row_lanes[kRows + 1];  // lanes whose voxel in row r exists and can be valid at all
 #pragma unroll
   for (int r = 0; r <= kRows; ++r)
+    row_lanes[r] = (y0 + r < p.Y && p.min_weight <= 65535) ? voxel_lanes : 0;
+  struct Masks
   {
-    w_lo[r] = in_x ? rowp[r][(size_t)zl0 * plane] : 0u;
-    n_lo[r] = __shfl_down(w_lo[r], 1, 64);
-  }
-  unsigned n_mine = 0;
-
-  for (int zl = zl0; zl < zl1; ++zl)
-  {
-    uint32_t w_hi[kRows + 1], n_hi[kRows + 1];
-    unsigned c_lo[kRows + 1], c_hi[kRows + 1];
+    uint64_t neg[kRows + 1], val[kRows + 1];
+  };
+  // (lanes past the row and rows past the volume hold some other voxel: never valid, sign ignored)
+  auto negative = [&](uint32_t w) { return __builtin_amdgcn_ballot_w64(half_bits_to_float(w & 0xffffu) < 0.f); };
+  auto any_negative = [&](const uint32_t(&w)[kRows + 1]) {
+    uint64_t any = 0;
 #pragma unroll
     for (int r = 0; r <= kRows; ++r)
-      w_hi[r] = in_x ? rowp[r][(size_t)(zl + 1) * plane] : 0u;
+      any |= negative(w[r]);
+    return any != 0;
+  };
+  auto classify = [&](const uint32_t(&w)[kRows + 1]) {
+    Masks m;
 #pragma unroll
     for (int r = 0; r <= kRows; ++r)
     {
-      n_hi[r] = __shfl_down(w_hi[r], 1, 64);
-      c_lo[r] = voxel_code(w_lo[r], p.min_weight) | (voxel_code(n_lo[r], p.min_weight) << 2);
-      c_hi[r] = voxel_code(w_hi[r], p.min_weight) | (voxel_code(n_hi[r], p.min_weight) << 2);
+      m.neg[r] = negative(w[r]);
+      m.val[r] = __builtin_amdgcn_ballot_w64(w[r] >= weight_thr) & row_lanes[r];
+    }
+    return m;
+  };
+
+  const uint32_t* layer = p.vol + (size_t)zl0 * plane;  // wave-uniform
+  uint32_t w_lo[kRows + 1];                             // layer z
+#pragma unroll
+  for (int r = 0; r <= kRows; ++r)
+    w_lo[r] = layer[row_off[r]];
+  // the loads run one layer ahead of the classification (two layers in flight per wave): with the
+  // branches below the compiler does not move them up by itself
+  layer += plane;
+  uint32_t w_ahead[kRows + 1];
+#pragma unroll
+  for (int r = 0; r <= kRows; ++r)
+    w_ahead[r] = layer[row_off[r]];
+  bool lo_negative = any_negative(w_lo);
+  unsigned n_mine = 0;
+
+  unsigned q_head = 0, q_count = 0;  // wave-uniform
+  auto drain = [&](unsigned n) {
+    __builtin_amdgcn_wave_barrier();
+    const unsigned slot = (q_head + (unsigned)lane) & 127u;
+    const bool mine = (unsigned)lane < n;
+    const uint64_t entry = mine ? ((uint64_t)queue[wave][5][slot] << 32) | queue[wave][4][slot] : 0;
+    const unsigned nt = (unsigned)(entry >> 60);
+    // exclusive scan of nt over the wave: where this lane's triangles go
+    unsigned incl = nt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+    {
+      const unsigned up = __shfl_up(incl, off, 64);
+      if (lane >= off)
+        incl += up;
+    }
+    const unsigned total = __shfl(incl, 63, 64);
+    if (nt != 0)
+    {
+      const unsigned place = queue[wave][6][slot];
+      const int cx = xt * kRun + (int)(place & 63u), gy = y0 + (int)((place >> 6) & 3u), gz = p.z0 + zl0 + (int)(place >> 8);
+      auto vertex = [&](unsigned e, float(&v)[3]) {
+        const unsigned c0 = (unsigned)(YAK_MC_EDGE_A >> (4 * e)) & 15u, c1 = (unsigned)(YAK_MC_EDGE_B >> (4 * e)) & 15u;
+        // corner values, marching_cubes.cpp:43-74: val = 5.0f * float(half)
+        const float v0 = 5.0f * half_bits_to_float((queue[wave][c0 >> 1][slot] >> (16u * (c0 & 1u))) & 0xffffu);
+        const float v1 = 5.0f * half_bits_to_float((queue[wave][c1 >> 1][slot] >> (16u * (c1 & 1u))) & 0xffffu);
+        // getOffset, :22-31: the double quotient of two floats rounded to float IS the fp32 quotient
+        // (53 >= 2 * 24 + 2), so the correctly rounded fp32 '/' gives the same value
+        const float delta = v1 - v0;
+        const float offset = delta == 0.f ? 0.5f : (0.0f - v0) / delta;
+        // :121-129  edge = v0_pos + offset * (v1_pos - v0_pos); the product is exact (factor 0 or +-1)
+        const float p0x = (float)(cx + (int)((kDxMask >> c0) & 1u)), p1x = (float)(cx + (int)((kDxMask >> c1) & 1u));
+        const float p0y = (float)(gy + (int)((kDyMask >> c0) & 1u)), p1y = (float)(gy + (int)((kDyMask >> c1) & 1u));
+        const float p0z = (float)(gz + (int)((kDzMask >> c0) & 1u)), p1z = (float)(gz + (int)((kDzMask >> c1) & 1u));
+        // :175-183  s * double(v), narrowed to float when the mesh cloud is filled
+        v[0] = (float)(p.scale * (double)(p0x + offset * (p1x - p0x)));
+        v[1] = (float)(p.scale * (double)(p0y + offset * (p1y - p0y)));
+        v[2] = (float)(p.scale * (double)(p0z + offset * (p1z - p0z)));
+      };
+      // a triangle per step: its three vertices are independent work (the chain of LDS reads, the
+      // division and the double products overlap), stored as three 12-byte pieces
+      struct __attribute__((packed, aligned(4))) Vertex
+      {
+        float v[3];
+      };
+      Vertex* dst = (Vertex*)(triangles + (out + (incl - nt)) * 9ull);
+      uint64_t edges = entry;
+      for (unsigned t = 0; t < nt; ++t, edges >>= 12, dst += 3)
+      {
+        Vertex a, b, c;
+        vertex((unsigned)edges & 15u, a.v);
+        vertex((unsigned)(edges >> 4) & 15u, b.v);
+        vertex((unsigned)(edges >> 8) & 15u, c.v);
+        dst[0] = a;
+        dst[1] = b;
+        dst[2] = c;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    out += total;
+    q_head = (q_head + n) & 127u;
+    q_count -= n;
+  };
+
+  for (int zl = zl0; zl < zl1; ++zl)
+  {
+    uint32_t w_hi[kRows + 1];
+    if (zl + 2 <= p.cube_layers)  // the last voxel layer of the slab at most
+      layer += plane;
+#pragma unroll
+    for (int r = 0; r <= kRows; ++r)
+    {
+      w_hi[r] = w_ahead[r];
+      w_ahead[r] = layer[row_off[r]];
+    }
+    const bool hi_negative = any_negative(w_hi);
+    const bool near_surface = lo_negative || hi_negative;  // wave-uniform
+    lo_negative = hi_negative;
+    Masks m_lo, m_hi;
+    if (near_surface)
+    {
+      m_lo = classify(w_lo);
+      m_hi = classify(w_hi);
     }
 
 #pragma unroll
     for (int r = 0; r < kRows; ++r)
     {
-      bool valid;
-      const unsigned ci = cube_index(c_lo[r], c_lo[r + 1], c_hi[r], c_hi[r + 1], valid);
-      const bool exists = has_cube && y0 + r + 1 < p.Y;
-      const uint64_t entry = (exists && valid) ? table[ci] : 0;
+      if (!near_surface)
+        break;
+      const uint64_t all4 = m_lo.neg[r] & m_lo.neg[r + 1] & m_hi.neg[r] & m_hi.neg[r + 1];
+      const uint64_t any4 = m_lo.neg[r] | m_lo.neg[r + 1] | m_hi.neg[r] | m_hi.neg[r + 1];
+      const uint64_t val4 = m_lo.val[r] & m_lo.val[r + 1] & m_hi.val[r] & m_hi.val[r + 1];
+      // ... and over the voxels at x and x + 1
+      const uint64_t surface = (any4 | (any4 >> 1)) & ~(all4 & (all4 >> 1)) & val4 & (val4 >> 1) & cube_lanes;
+      if (surface == 0)  // wave-uniform
+        continue;
+
+      // the words at x + 1, and the cube's case: marching_cubes.cpp:43-96
+      const uint32_t na_lo = __shfl_down(w_lo[r], 1, 64), nb_lo = __shfl_down(w_lo[r + 1], 1, 64);
+      const uint32_t na_hi = __shfl_down(w_hi[r], 1, 64), nb_hi = __shfl_down(w_hi[r + 1], 1, 64);
+      const unsigned a_lo = voxel_code(w_lo[r], p.min_weight) | (voxel_code(na_lo, p.min_weight) << 2);
+      const unsigned b_lo = voxel_code(w_lo[r + 1], p.min_weight) | (voxel_code(nb_lo, p.min_weight) << 2);
+      const unsigned a_hi = voxel_code(w_hi[r], p.min_weight) | (voxel_code(na_hi, p.min_weight) << 2);
+      const unsigned b_hi = voxel_code(w_hi[r + 1], p.min_weight) | (voxel_code(nb_hi, p.min_weight) << 2);
+      bool valid_cube;
+      const unsigned ci = cube_index(a_lo, b_lo, a_hi, b_hi, valid_cube);
+      const uint64_t entry = ((surface >> lane) & 1u) && valid_cube ? table[ci] : 0;
       const unsigned nt = (unsigned)(entry >> 60);
 
       if (!EMIT)
         n_mine += nt;
-      else if (__builtin_amdgcn_ballot_w64(nt != 0) != 0)
+      else
       {
-        // exclusive scan of nt over the wave: where this lane's triangles go
-        unsigned incl = nt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1)
-        {
-          const unsigned up = __shfl_up(incl, off, 64);
-          if (lane >= off)
-            incl += up;
-        }
-        const unsigned total = __shfl(incl, 63, 64);
+        // queue the cubes that hold triangles; they are worked off 64 at a time, whichever rows and layers
+        // they come from (a curved surface crosses a row in a handful of cubes: emitting row by row kept
+        // a few lanes of the wave busy)
+        const uint64_t holders = __builtin_amdgcn_ballot_w64(nt != 0);
         if (nt != 0)
         {
-          // corner values, marching_cubes.cpp:43-74: val = 5.0f * float(half)
-          vals[wave][0][lane] = 5.0f * half_bits_to_float(n_lo[r + 1] & 0xffffu);
-          vals[wave][1][lane] = 5.0f * half_bits_to_float(n_lo[r] & 0xffffu);
-          vals[wave][2][lane] = 5.0f * half_bits_to_float(w_lo[r] & 0xffffu);
-          vals[wave][3][lane] = 5.0f * half_bits_to_float(w_lo[r + 1] & 0xffffu);
-          vals[wave][4][lane] = 5.0f * half_bits_to_float(n_hi[r + 1] & 0xffffu);
-          vals[wave][5][lane] = 5.0f * half_bits_to_float(n_hi[r] & 0xffffu);
-          vals[wave][6][lane] = 5.0f * half_bits_to_float(w_hi[r] & 0xffffu);
-          vals[wave][7][lane] = 5.0f * half_bits_to_float(w_hi[r + 1] & 0xffffu);
-          float* dst = triangles + (out + (incl - nt)) * 9ull;
-          const int gy = y0 + r, gz = p.z0 + zl;
-          for (unsigned k = 0; k < 3 * nt; ++k)
-          {
-            const unsigned e = (unsigned)(entry >> (4 * k)) & 15u;
-            const unsigned c0 = (unsigned)(YAK_MC_EDGE_A >> (4 * e)) & 15u, c1 = (unsigned)(YAK_MC_EDGE_B >> (4 * e)) & 15u;
-            const float v0 = vals[wave][c0][lane], v1 = vals[wave][c1][lane];
-            // getOffset, :22-31: the double quotient of two floats rounded to float IS the fp32 quotient
-            // (53 >= 2 * 24 + 2), so the correctly rounded fp32 '/' gives the same value
-            const float delta = v1 - v0;
-            const float offset = delta == 0.f ? 0.5f : (0.0f - v0) / delta;
-            // :121-129  edge = v0_pos + offset * (v1_pos - v0_pos); the product is exact (factor 0 or +-1)
-            const float p0x = (float)(x + (int)((kDxMask >> c0) & 1u)), p1x = (float)(x + (int)((kDxMask >> c1) & 1u));
-            const float p0y = (float)(gy + (int)((kDyMask >> c0) & 1u)), p1y = (float)(gy + (int)((kDyMask >> c1) & 1u));
-            const float p0z = (float)(gz + (int)((kDzMask >> c0) & 1u)), p1z = (float)(gz + (int)((kDzMask >> c1) & 1u));
-            // :175-183  s * double(v), narrowed to float when the mesh cloud is filled
-            dst[3 * k + 0] = (float)(p.scale * (double)(p0x + offset * (p1x - p0x)));
-            dst[3 * k + 1] = (float)(p.scale * (double)(p0y + offset * (p1y - p0y)));
-            dst[3 * k + 2] = (float)(p.scale * (double)(p0z + offset * (p1z - p0z)));
-          }
+          const unsigned before = __builtin_amdgcn_mbcnt_hi((uint32_t)(holders >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)holders, 0u));
+          const unsigned slot = (q_head + q_count + before) & 127u;
+          queue[wave][0][slot] = (nb_lo & 0xffffu) | (na_lo << 16);          // corners 0, 1
+          queue[wave][1][slot] = (w_lo[r] & 0xffffu) | (w_lo[r + 1] << 16);  // corners 2, 3
+          queue[wave][2][slot] = (nb_hi & 0xffffu) | (na_hi << 16);          // corners 4, 5
+          queue[wave][3][slot] = (w_hi[r] & 0xffffu) | (w_hi[r + 1] << 16);  // corners 6, 7
+          queue[wave][4][slot] = (uint32_t)entry;
+          queue[wave][5][slot] = (uint32_t)(entry >> 32);
+          queue[wave][6][slot] = (unsigned)lane | ((unsigned)r << 6) | ((unsigned)(zl - zl0) << 8);
         }
-        out += total;
+        q_count += (unsigned)__builtin_popcountll(holders);
+        if (q_count >= 64u)
+          drain(64u);
       }
     }
 #pragma unroll
     for (int r = 0; r <= kRows; ++r)
-    {
       w_lo[r] = w_hi[r];
-      n_lo[r] = n_hi[r];
-    }
     if (!EMIT && ((zl + 1 - zl0) % p.z_sub == 0 || zl + 1 == zl1))  // wave-uniform: a tile is complete
     {
 #pragma unroll
@@ -199,6 +334,8 @@ __global__ __launch_bounds__(256) void mc_kernel(const McParams p, uint32_t* cou
       n_mine = 0;
     }
   }
+  if (EMIT && q_count != 0)
+    drain(q_count);
 }
 
 // Exclusive scan of the tile counts in two small launches: every workgroup scans kScanBlock counts
@@ -285,18 +422,20 @@ int launch_marching_cubes(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, in
   *n_out = 0;
   if (X < 2 || Y < 2 || layers < 2)
     return 0;  // no cube fits (marching_cubes.cpp:164-168: the loops do not run)
+  if ((unsigned long long)X * (unsigned long long)Y > (1ull << 30))
+    return fail(YAKHIP_ERANGE, "marching_cubes: a layer of more than 2^30 voxels");  // 32-bit offsets within a layer
   McParams p;
   p.vol = vol;
   p.X = X, p.Y = Y, p.z0 = z0;
   p.cube_layers = layers - 1;
   p.nx = (X - 1 + kRun - 1) / kRun;
   p.ny = (Y - 1 + kRows - 1) / kRows;
-  // tiles of 4 cube layers, walked 4 at a time by the count pass (measured at 512^3: the count pass wants
-  // long walks, 0.18 ms at 32 layers vs 0.28 at 8; the emit pass wants many short waves, 0.21 vs 0.53 ms)
-  p.z_sub = ctx->mc_z_chunk > 0 ? ctx->mc_z_chunk : 4;
-  while ((p.cube_layers + p.z_sub - 1) / p.z_sub > 65535)
-    p.z_sub *= 2;
-  p.z_chunk = 4 * p.z_sub;
+  // tiles of 8 cube layers; the count pass walks 16 layers (two tiles) per wave.  Measured at 512^3 on the
+  // orbit scene: count 0.117 ms for walks of 16, 0.17 for 32 (too few waves); emit 0.090 ms at 8 layers
+  // per tile, 0.094 at 4, 0.115 at 2 and at 16 (short tiles fill the cube queue badly, long ones leave
+  // too few waves)
+  p.z_sub = ctx->mc_z_chunk > 0 ? ctx->mc_z_chunk : 8;
+  p.z_chunk = p.z_sub * std::max(1, 16 / p.z_sub);
   p.nzs = (p.cube_layers + p.z_sub - 1) / p.z_sub;
   p.nzc = (p.cube_layers + p.z_chunk - 1) / p.z_chunk;
   p.min_weight = min_weight;
@@ -330,7 +469,10 @@ int launch_marching_cubes(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, in
   unsigned long long* block_bases = (unsigned long long*)((uint8_t*)ctx->mc_scratch + 2 * counts_bytes);
   unsigned long long* total = block_bases + n_blocks;
 
-  const dim3 grid((unsigned)p.nx, gy, (unsigned)p.nzc), grid_emit((unsigned)p.nx, gy, (unsigned)p.nzs);
+  const size_t wgs_layer = (size_t)p.nx * gy;
+  if (wgs_layer * (size_t)p.nzs > 0x7fffffffull)
+    return fail(YAKHIP_ERANGE, "marching_cubes: more than 2^31 workgroups");
+  const dim3 grid((unsigned)(wgs_layer * p.nzc)), grid_emit((unsigned)(wgs_layer * p.nzs));
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   int rc = timing_begin(ctx, &ev);  // one event pair around count + scan (+ the emit pass below gets its own)
   if (rc != 0)
