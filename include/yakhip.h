@@ -175,6 +175,45 @@ int yakhip_raycast_depth(yakhip_ctx* ctx, const yakhip_volume* vol, const float 
                          void* depth_dev, size_t depth_pitch, void* normals_dev, size_t normals_pitch, int rows,
                          int cols);
 
+/* Ray casting over a z-slab of a volume that is spread over several GPUs (option 1).  No
+ * counterpart in the reference, which ray-casts one whole volume (tsdf_volume.cu:288-352); the arithmetic
+ * is that kernel's.  `vol` describes the layers this GPU HOLDS, [vol->z0, vol->z1): its own layers
+ * [z_own0, z_own1) plus a halo of at least yakhip_raycast_halo() layers on either side (fewer only where
+ * the volume ends).  Every GPU marches every ray over the same global sample sequence and examines the
+ * sample pairs whose first sample falls into one of its own layers.  Outputs, per pixel:
+ *   keys (int32 image, pitch multiple of 4): 2 * k + f, k = index of the first pair among the slab's own
+ *     that ends the march (zero crossing, or the - to + abort of tsdf_volume.cu:328-329); 0x7fffffff if no
+ *     own pair ends the march.  f = 1: the hit's refined point lies outside the held layers (the secant
+ *     step of tsdf_volume.cu:338 extrapolates when the trilinear values at the two samples have the same
+ *     sign), so its normal is still to be computed -- see yakhip_raycast_resolve;
+ *   points / depth / normals: as yakhip_raycast_points / _depth write them for that pair (NaN resp. 0
+ *     for an abort or no event); for f = 1 the vertex / depth is final unless the normal turns out NaN,
+ *     and the normals image holds the refined point in VOLUME coordinates.  points_dev or depth_dev may
+ *     be NULL.
+ * Composite: the pixel's result is the payload of the slab with the smallest key (keys of different
+ * slabs never tie).  Then every slab calls yakhip_raycast_resolve on the composited images and the
+ * pixels it changed (its key went from odd to even) are composited once more.  The result equals the
+ * whole-volume raycast bit for bit.  yak_amd/shard.py:composite_raycast does both steps with
+ * all-reduces. */
+int yakhip_raycast_slab(yakhip_ctx* ctx, const yakhip_volume* vol, int z_own0, int z_own1, const float R[9],
+                        const float t[3], const float Rinv[9], const float intr[4], float step_factor,
+                        float gradient_delta_factor, void* points_dev, size_t points_pitch, void* depth_dev,
+                        size_t depth_pitch, void* normals_dev, size_t normals_pitch, void* keys_dev, size_t keys_pitch,
+                        int rows, int cols);
+/* Second step of the slab composite.  points / depth / normals / keys: the COMPOSITED images (the same on
+ * every GPU).  For every pixel with an odd key whose refined point (read from the normals image) lies
+ * in one of this slab's own layers: compute the normal there (tsdf_volume.cu:354-372), write it -- or,
+ * if it is NaN, discard the hit as tsdf_volume.cu:340-348 does: NaN vertex and normal, depth 0 -- and
+ * clear the key's low bit.  Other pixels are left alone.  Needs ceil(gradient delta / voxel_z) + 2 halo
+ * layers, which yakhip_raycast_slab's halo covers.  Not blocking. */
+int yakhip_raycast_resolve(yakhip_ctx* ctx, const yakhip_volume* vol, int z_own0, int z_own1, const float Rinv[9],
+                           float gradient_delta_factor, void* points_dev, size_t points_pitch, void* depth_dev,
+                           size_t depth_pitch, void* normals_dev, size_t normals_pitch, void* keys_dev, size_t keys_pitch,
+                           int rows, int cols);
+/* Halo layers yakhip_raycast_slab needs: ceil(step / voxel_z) + ceil(gradient delta / voxel_z) + 2.
+ * vol->data, z0, z1 are not looked at beyond the usual validity checks. */
+int yakhip_raycast_halo(const yakhip_volume* vol, float step_factor, float gradient_delta_factor, int* layers);
+
 /* ---- tracking side: depth pre-processing and projective ICP ------------
  * Depth images: uint16 millimetres; point / normal maps: float4 {x, y, z, w}, NaN = no data.  All
  * row-pitched (pitch in bytes; multiple of 2 resp. 16). */
@@ -217,6 +256,19 @@ int yakhip_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], c
                           const void* ncurr_dev, size_t ncurr_pitch, const void* vprev_dev, size_t vprev_pitch,
                           const void* nprev_dev, size_t nprev_pitch, int rows, int cols, float sums_host[27],
                           int counts_host[6]);
+
+/* The same sums over the rows [row_begin, row_end) of the CURRENT maps only (the previous maps are read
+ * wherever the correspondences fall), left on the device and NOT waited for: sums_dev receives 33 floats,
+ * the 27 sums followed by the 6 counts (exact as floats below 2^24).  No counterpart in the reference;
+ * it is the piece SURVEY.md 8e's image-space split needs: every GPU takes a band of rows, the 33 values
+ * are added over the GPUs (an all-reduce, yak_amd/sharding.py:allreduce_icp_sums), every GPU solves the
+ * same 6 x 6 system.  The order of the additions differs from the one-GPU sum, so A and b agree to
+ * rounding (1e-4 relative), not bit for bit.  row_begin == row_end gives zeros. */
+int yakhip_icp_accumulate_rows(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], int level,
+                               float dist_thres, float angle_thres, const void* vcurr_dev, size_t vcurr_pitch,
+                               const void* ncurr_dev, size_t ncurr_pitch, const void* vprev_dev, size_t vprev_pitch,
+                               const void* nprev_dev, size_t nprev_pitch, int rows, int cols, int row_begin,
+                               int row_end, float* sums_dev);
 
 /* One pyramid level of an ICP problem: the current frame's maps, the previous (model) maps, their size
  * and the number of linearisations to run on it (ProjectiveICP::iters_, projective_icp.cpp:87-96). */

@@ -67,6 +67,8 @@ def lib():
         L.yko_raycast.argtypes = [_u32p, _i32p, _f32p, C.c_float, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_float,
                                   C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                   C.c_size_t, _u64p, C.c_int]
+        L.yko_raycast_slab.restype = None
+        L.yko_raycast_slab.argtypes = L.yko_raycast.argtypes + [C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         vp, sz, i, f = C.c_void_p, C.c_size_t, C.c_int, C.c_float
         L.yko_bilateral_filter.restype = None
         L.yko_bilateral_filter.argtypes = [vp, sz, vp, sz, i, i, i, f, f]
@@ -170,6 +172,29 @@ def raycast(volume, dims, voxel_size, trunc_dist, R, t, Rinv, intr, rows, cols, 
         points.ctypes.data if points is not None else None, cols * 16, normals.ctypes.data, cols * 16,
         depth.ctypes.data if depth is not None else None, cols * 2, stats, int(nthreads))
     return (depth if want_depth else points), normals, int(stats[0]), int(stats[1])
+
+
+def raycast_slab(volume, dims, voxel_size, trunc_dist, R, t, Rinv, intr, rows, cols, z_own0, z_own1, step_factor=0.75,
+                 gradient_delta_factor=0.5, want_depth=False, nthreads=1):
+    """The march of `raycast` restricted to the sample pairs whose first sample lies in the layers
+    [z_own0, z_own1) (the whole volume is still passed).  Returns (points|depth, normals, keys): keys is
+    (rows, cols) int32, 2 * index of the march-ending pair or INT32_MAX."""
+    dims = np.ascontiguousarray(dims, dtype=np.int32)
+    assert volume.dtype == np.uint32 and volume.flags.c_contiguous
+    assert volume.size == int(dims[0]) * int(dims[1]) * int(dims[2])
+    normals = np.empty((rows, cols, 4), dtype=np.float32)
+    points = None if want_depth else np.empty((rows, cols, 4), dtype=np.float32)
+    depth = np.empty((rows, cols), dtype=np.uint16) if want_depth else None
+    keys = np.empty((rows, cols), dtype=np.int32)
+    stats = np.zeros(2, dtype=np.uint64)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32).reshape(-1)  # noqa: E731
+    lib().yko_raycast_slab(
+        volume.reshape(-1), dims, f32(voxel_size), float(trunc_dist), f32(R), f32(t), f32(Rinv), f32(intr),
+        float(step_factor), float(gradient_delta_factor), int(rows), int(cols),
+        points.ctypes.data if points is not None else None, cols * 16, normals.ctypes.data, cols * 16,
+        depth.ctypes.data if depth is not None else None, cols * 2, stats, int(nthreads), int(z_own0), int(z_own1),
+        keys.ctypes.data, cols * 4)
+    return (depth if want_depth else points), normals, keys
 
 
 def _u16img(a):

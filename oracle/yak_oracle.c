@@ -340,8 +340,13 @@ static void compute_normal(const Raycaster* rc, float px, float py, float pz, fl
 
 /* One pixel: cu:288-352 (and :220-285, which differs only in what is stored).
  * Returns 1 and fills vertex (camera frame) / normal on a hit. */
-static int raycast_pixel(const Raycaster* rc, int x, int y, float vertex[3], float normal[3], uint64_t* fetches)
+static int raycast_pixel(const Raycaster* rc, int x, int y, float vertex[3], float normal[3], uint64_t* fetches,
+                         int z_own0, int z_own1, int* key)
 {
+  /* Slab form (no counterpart in the reference; SURVEY.md 8e option 1): the same march, but a sample pair
+   * is examined only if its first sample's nearest layer lies in [z_own0, z_own1).  *key = 2 * index of
+   * the pair that ended the march, or INT32_MAX.  With [0, Z) this is the reference's march. */
+  *key = 0x7fffffff;
   const float* R = rc->R;
   const float* t = rc->t;
   /* cu:300-301  ray_dir = normalized(aff.R * reproj(x, y, 1.f));  device.hpp:57-62 */
@@ -377,18 +382,27 @@ static int raycast_pixel(const Raycaster* rc, int x, int y, float vertex[3], flo
 
   /* cu:320-351 */
   float tsdf_next = fetch_tsdf(rc, nx, ny, nz, fetches);
-  for (float tcurr = tmin; tcurr < tmax; tcurr += ts)
+  int pair = 0;
+  for (float tcurr = tmin; tcurr < tmax; tcurr += ts, ++pair)
   {
     const float tsdf_curr = tsdf_next;
     const float cxp = nx, cyp = ny, czp = nz;
+    const int zc = clampi((int)nearbyintf(czp * rc->ivz), rc->Z - 1);
+    const int own = zc >= z_own0 && zc < z_own1;
     nx += sx;
     ny += sy;
     nz += sz;
     tsdf_next = fetch_tsdf(rc, nx, ny, nz, fetches);
+    if (!own)
+      continue;
     if (tsdf_curr < 0.f && tsdf_next > 0.f)
+    {
+      *key = 2 * pair;
       return 0;
+    }
     if (tsdf_curr > 0.f && tsdf_next < 0.f)
     {
+      *key = 2 * pair;
       const float Ft = interpolate(rc, cxp * rc->ivx, cyp * rc->ivy, czp * rc->ivz);
       const float Ftdt = interpolate(rc, nx * rc->ivx, ny * rc->ivy, nz * rc->ivz);
       const float Ts = tcurr - (ts * Ft) / (Ftdt - Ft);
@@ -417,6 +431,18 @@ void yko_raycast(const uint32_t* volume, const int dims[3], const float voxel_si
                  size_t points_pitch_bytes, float* normals, size_t normals_pitch_bytes, uint16_t* depth,
                  size_t depth_pitch_bytes, uint64_t stats[2], int nthreads)
 {
+  yko_raycast_slab(volume, dims, voxel_size, trunc_dist, R, t, Rinv, intr, raycast_step_factor, gradient_delta_factor,
+                   rows, cols, points, points_pitch_bytes, normals, normals_pitch_bytes, depth, depth_pitch_bytes, stats,
+                   nthreads, 0, dims[2], NULL, 0);
+}
+
+void yko_raycast_slab(const uint32_t* volume, const int dims[3], const float voxel_size[3], float trunc_dist,
+                      const float R[9], const float t[3], const float Rinv[9], const float intr[4],
+                      float raycast_step_factor, float gradient_delta_factor, int rows, int cols, float* points,
+                      size_t points_pitch_bytes, float* normals, size_t normals_pitch_bytes, uint16_t* depth,
+                      size_t depth_pitch_bytes, uint64_t stats[2], int nthreads, int z_own0, int z_own1, int32_t* keys,
+                      size_t keys_pitch_bytes)
+{
   Raycaster rc;
   rc.vol = volume;
   rc.X = dims[0], rc.Y = dims[1], rc.Z = dims[2];
@@ -442,8 +468,11 @@ void yko_raycast(const uint32_t* volume, const int dims[3], const float voxel_si
     for (int x = 0; x < cols; ++x)
     {
       float v[3], n[3];
-      const int hit = raycast_pixel(&rc, x, y, v, n, &fetches);
+      int key;
+      const int hit = raycast_pixel(&rc, x, y, v, n, &fetches, z_own0, z_own1, &key);
       hits += (uint64_t)hit;
+      if (keys)
+        ((int32_t*)((char*)keys + (size_t)y * keys_pitch_bytes))[x] = key;
       if (hit)
       {
         nrow[4 * x + 0] = n[0], nrow[4 * x + 1] = n[1], nrow[4 * x + 2] = n[2], nrow[4 * x + 3] = 0.f;

@@ -83,6 +83,18 @@ void yko_raycast(const uint32_t* volume, const int dims[3], const float voxel_si
                  size_t points_pitch_bytes, float* normals, size_t normals_pitch_bytes, uint16_t* depth,
                  size_t depth_pitch_bytes, uint64_t stats[2], int nthreads);
 
+/* The same march restricted to a z-slab's own layers [z_own0, z_own1) of the (whole) volume: a sample
+ * pair is examined only if its first sample's nearest layer is one of them.  No counterpart in the
+ * reference: it is the checker for yakhip_raycast_slab, whose per-slab results composite (smallest key
+ * wins) into yko_raycast's image.  keys (int32 image, may be NULL) = 2 * index of the pair that ended
+ * the march, INT32_MAX if none did. */
+void yko_raycast_slab(const uint32_t* volume, const int dims[3], const float voxel_size[3], float trunc_dist,
+                      const float R[9], const float t[3], const float Rinv[9], const float intr[4],
+                      float raycast_step_factor, float gradient_delta_factor, int rows, int cols, float* points,
+                      size_t points_pitch_bytes, float* normals, size_t normals_pitch_bytes, uint16_t* depth,
+                      size_t depth_pitch_bytes, uint64_t stats[2], int nthreads, int z_own0, int z_own1, int32_t* keys,
+                      size_t keys_pitch_bytes);
+
 /* ---- pre-processing of the depth frame for ICP: src/cuda/imgproc.cu ------------------------- */
 
 /* imgproc.cu:10-56 (bilateral_kernel + device::bilateralFilter).  sigma_depth in metres (scaled to mm

@@ -135,3 +135,52 @@ def test_golden_fixture_raycast_s1_32():
     assert fetches == int(g["fetches"]) and hits == int(g["hits"])
     assert np.array_equal(pts.view(np.uint32), g["points"])
     assert np.array_equal(nrm.view(np.uint32), g["normals"])
+
+
+def fused_orbit_volume(n, frames):
+    dims, vs, tr = synth.volume_geometry(n)
+    vol = np.zeros(int(np.prod(dims)), dtype=np.uint32)
+    for f in frames:
+        depth, R, t = synth.scene_s2(f)
+        oracle.integrate(vol, dims, vs, tr, synth.MAX_WEIGHT, oracle.compute_dists(depth, synth.INTR), R, t, synth.INTR,
+                         nthreads=8)
+    return vol, dims, vs, tr
+
+
+def composite_min_key(parts):
+    """Reference composite of per-slab results [(points, normals, keys)]: smallest key owns the pixel."""
+    keys = np.stack([k for _, _, k in parts])
+    best = keys.min(axis=0)
+    assert ((keys == best).sum(axis=0)[best != 0x7FFFFFFF] == 1).all()          # keys of different slabs never tie
+    win = keys.argmin(axis=0)
+    pts = np.take_along_axis(np.stack([p for p, _, _ in parts]), win[None, ..., None], axis=0)[0]
+    nrm = np.take_along_axis(np.stack([n for _, n, _ in parts]), win[None, ..., None], axis=0)[0]
+    return pts, nrm, best
+
+
+def test_slab_marches_composite_to_the_whole_march():
+    """SURVEY.md 8e option 1 on the CPU: every slab marches every ray and examines the pairs it owns;
+    the first march-ending pair over all slabs is the one the whole-volume march stops at."""
+    vol, dims, vs, tr = fused_orbit_volume(48, [0, 60, 120, 180, 240])
+    rows, cols = 60, 80
+    intr = (72.5, 72.5, 39.5, 29.5)
+    later = False
+    for frame in (20, 100, 215):
+        _, R_v2c, t_v2c = synth.scene_s2(frame)
+        R, t = _cam2vol(R_v2c, t_v2c)
+        Rinv = np.ascontiguousarray(R.T)
+        pts, nrm, _, hits = oracle.raycast(vol, dims, vs, tr, R, t, Rinv, intr, rows, cols, nthreads=4)
+        assert hits > 500
+        whole_p, whole_n, whole_k = oracle.raycast_slab(vol, dims, vs, tr, R, t, Rinv, intr, rows, cols, 0, dims[2], nthreads=4)
+        assert np.array_equal(whole_p.view(np.uint32), pts.view(np.uint32))
+        assert (whole_k[~np.isnan(pts[..., 0])] != 0x7FFFFFFF).all() and (whole_k % 2 == (whole_k == 0x7FFFFFFF)).all()
+        for cuts in ([0, 24, 48], [0, 7, 19, 20, 41, 48], [0, 1, 47, 48]):
+            parts = [oracle.raycast_slab(vol, dims, vs, tr, R, t, Rinv, intr, rows, cols, a, b, nthreads=4)
+                     for a, b in zip(cuts, cuts[1:])]
+            cp, cn, ck = composite_min_key(parts)
+            assert np.array_equal(ck, whole_k)
+            assert np.array_equal(cp.view(np.uint32), pts.view(np.uint32))
+            assert np.array_equal(cn.view(np.uint32), nrm.view(np.uint32))
+            # a slab on its own sees later pairs too (the march went on where another slab's pair had ended it)
+            later = later or any((k[(k != 0x7FFFFFFF)] > whole_k[(k != 0x7FFFFFFF)]).any() for _, _, k in parts)
+    assert later

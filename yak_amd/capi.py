@@ -17,9 +17,10 @@ EXPORTS = [
     "yakhip_malloc", "yakhip_malloc_pitch", "yakhip_free", "yakhip_upload", "yakhip_download",
     "yakhip_upload_2d", "yakhip_download_2d",
     "yakhip_clear_volume", "yakhip_compute_dists", "yakhip_integrate", "yakhip_integrate_batch",
-    "yakhip_raycast_points", "yakhip_raycast_depth",
+    "yakhip_raycast_points", "yakhip_raycast_depth", "yakhip_raycast_slab", "yakhip_raycast_resolve", "yakhip_raycast_halo",
     "yakhip_bilateral_filter", "yakhip_truncate_depth", "yakhip_depth_pyramid", "yakhip_compute_points_normals",
-    "yakhip_resize_points_normals", "yakhip_icp_accumulate", "yakhip_icp_estimate", "yakhip_marching_cubes",
+    "yakhip_resize_points_normals", "yakhip_icp_accumulate", "yakhip_icp_accumulate_rows", "yakhip_icp_estimate",
+    "yakhip_marching_cubes",
 ]
 
 
@@ -103,6 +104,11 @@ def load():
         "yakhip_integrate_batch": [vp, volp, C.POINTER(FrameDesc), i],
         "yakhip_raycast_points": [vp, volp, fp, fp, fp, fp, C.c_float, C.c_float, vp, sz, vp, sz, i, i],
         "yakhip_raycast_depth": [vp, volp, fp, fp, fp, fp, C.c_float, C.c_float, vp, sz, vp, sz, i, i],
+        "yakhip_raycast_slab": [vp, volp, i, i, fp, fp, fp, fp, C.c_float, C.c_float, vp, sz, vp, sz, vp, sz, vp, sz, i, i],
+        "yakhip_raycast_halo": [volp, C.c_float, C.c_float, C.POINTER(i)],
+        "yakhip_raycast_resolve": [vp, volp, i, i, fp, C.c_float, vp, sz, vp, sz, vp, sz, vp, sz, i, i],
+        "yakhip_icp_accumulate_rows": [vp, fp, fp, fp, i, C.c_float, C.c_float, vp, sz, vp, sz, vp, sz, vp, sz, i, i, i, i,
+                                       vp],
         "yakhip_bilateral_filter": [vp, vp, sz, vp, sz, i, i, i, C.c_float, C.c_float],
         "yakhip_truncate_depth": [vp, vp, sz, i, i, C.c_float],
         "yakhip_depth_pyramid": [vp, vp, sz, i, i, vp, sz, C.c_float],
@@ -220,6 +226,24 @@ class Context:
                                          step_factor, gradient_delta_factor, C.c_void_p(depth_ptr), depth_pitch,
                                          C.c_void_p(normals_ptr), normals_pitch, rows, cols))
 
+    def raycast_slab(self, vol, z_own0, z_own1, R, t, Rinv, intr, keys_ptr, keys_pitch, normals_ptr, normals_pitch, rows,
+                     cols, points_ptr=None, points_pitch=0, depth_ptr=None, depth_pitch=0, step_factor=0.75,
+                     gradient_delta_factor=0.5):
+        """vol = the layers HELD (own + halo); [z_own0, z_own1) = the slab's own.  See include/yakhip.h."""
+        _chk(load().yakhip_raycast_slab(self._h, C.byref(vol), int(z_own0), int(z_own1), _f32(R, 9), _f32(t, 3),
+                                        _f32(Rinv, 9), _f32(intr, 4), step_factor, gradient_delta_factor,
+                                        C.c_void_p(points_ptr), points_pitch, C.c_void_p(depth_ptr), depth_pitch,
+                                        C.c_void_p(normals_ptr), normals_pitch, C.c_void_p(keys_ptr), keys_pitch, rows,
+                                        cols))
+
+    def raycast_resolve(self, vol, z_own0, z_own1, Rinv, keys_ptr, keys_pitch, normals_ptr, normals_pitch, rows, cols,
+                        points_ptr=None, points_pitch=0, depth_ptr=None, depth_pitch=0, gradient_delta_factor=0.5):
+        """Second step of the slab composite, on the composited images.  See include/yakhip.h."""
+        _chk(load().yakhip_raycast_resolve(self._h, C.byref(vol), int(z_own0), int(z_own1), _f32(Rinv, 9),
+                                           gradient_delta_factor, C.c_void_p(points_ptr), points_pitch,
+                                           C.c_void_p(depth_ptr), depth_pitch, C.c_void_p(normals_ptr), normals_pitch,
+                                           C.c_void_p(keys_ptr), keys_pitch, rows, cols))
+
     # ---- tracking side ----
     def bilateral_filter(self, src_ptr, src_pitch, dst_ptr, dst_pitch, rows, cols, kernel_size, sigma_spatial,
                          sigma_depth):
@@ -255,6 +279,16 @@ class Context:
                                           nprev_pitch, rows, cols, sums, counts))
         return list(sums), list(counts)
 
+    def icp_accumulate_rows(self, R, t, intr, level, dist_thres, angle_thres, vcurr_ptr, vcurr_pitch, ncurr_ptr,
+                            ncurr_pitch, vprev_ptr, vprev_pitch, nprev_ptr, nprev_pitch, rows, cols, row_begin, row_end,
+                            sums_dev_ptr):
+        """Not blocking: 33 floats (27 sums, 6 counts) for rows [row_begin, row_end) go to device memory."""
+        _chk(load().yakhip_icp_accumulate_rows(self._h, _f32(R, 9), _f32(t, 3), _f32(intr, 4), int(level), dist_thres,
+                                               angle_thres, C.c_void_p(vcurr_ptr), vcurr_pitch, C.c_void_p(ncurr_ptr),
+                                               ncurr_pitch, C.c_void_p(vprev_ptr), vprev_pitch, C.c_void_p(nprev_ptr),
+                                               nprev_pitch, rows, cols, int(row_begin), int(row_end),
+                                               C.c_void_p(sums_dev_ptr)))
+
     def icp_estimate(self, R, t, intr, dist_thres, angle_thres, levels):
         """levels: per pyramid level l = 0.. a tuple (vcurr_ptr, ncurr_ptr, vprev_ptr, nprev_ptr, pitch, rows, cols,
         iterations).  Blocking.  Returns (R 3x3 list, t list, ok)."""
@@ -274,6 +308,13 @@ class Context:
         _chk(load().yakhip_marching_cubes(self._h, C.byref(vol), int(min_weight), float(scale),
                                           C.c_void_p(triangles_ptr or 0), int(capacity), C.byref(n)))
         return n.value
+
+
+def raycast_halo(vol, step_factor=0.75, gradient_delta_factor=0.5):
+    """Halo layers a slab needs on either side for yakhip_raycast_slab."""
+    n = C.c_int(0)
+    _chk(load().yakhip_raycast_halo(C.byref(vol), step_factor, gradient_delta_factor, C.byref(n)))
+    return n.value
 
 
 def volume_desc(data_ptr, dims, voxel_size, trunc_dist, max_weight, z0=0, z1=None):

@@ -518,17 +518,31 @@ int yakhip_integrate_batch(yakhip_ctx* ctx, const yakhip_volume* vol, const yakh
   return launch_integrate_batch(ctx, ps.data(), n_frames);
 }
 
+// layers of halo a slab needs on either side so that a march-ending pair and its refinement read held voxels
+// only: the next sample is at most ceil(step / voxel) + 1 layers from the owned one, the trilinear taps one
+// more, the gradient taps ceil(delta / voxel) more
+static int raycast_halo_layers(const yakhip_volume* vol, float step_factor, float gradient_delta_factor)
+{
+  const float vs = vol->voxel_size[2];
+  const double step = (double)(vol->trunc_dist * step_factor) / vs, delta = (double)(vs * gradient_delta_factor) / vs;
+  const double h = ceil(step) + ceil(delta) + 2.0;
+  return h < 1e9 ? (int)h : 1000000000;
+}
+
+// keys == nullptr: the whole volume (vol->z0 = 0, vol->z1 = dims[2]).  Otherwise slab mode: vol holds the
+// layers [z0, z1), of which [z_own0, z_own1) are the slab's own.
 static int raycast_common(yakhip_ctx* ctx, const yakhip_volume* vol, const float R[9], const float t[3],
                           const float Rinv[9], const float intr[4], float step_factor, float gradient_delta_factor,
                           void* points, size_t points_pitch, void* depth, size_t depth_pitch, void* normals,
-                          size_t normals_pitch, int rows, int cols)
+                          size_t normals_pitch, int rows, int cols, void* keys = nullptr, size_t keys_pitch = 0,
+                          int z_own0 = 0, int z_own1 = 0)
 {
   int rc = enter(ctx);
   if (rc != 0)
     return rc;
   if ((rc = check_volume(vol)) != 0)
     return rc;
-  if (vol->z0 != 0 || vol->z1 != vol->dims[2])
+  if (!keys && (vol->z0 != 0 || vol->z1 != vol->dims[2]))
     return fail(YAKHIP_EINVAL, "raycast: needs the whole volume, got the slab [%d, %d) of %d layers", vol->z0, vol->z1,
                 vol->dims[2]);
   if (!R || !t || !Rinv || !intr)
@@ -541,6 +555,18 @@ static int raycast_common(yakhip_ctx* ctx, const yakhip_volume* vol, const float
     return rc;
   if (depth && (rc = check_image("raycast(depth)", depth, depth_pitch, rows, cols, 2)) != 0)
     return rc;
+  if (keys)
+  {
+    if ((rc = check_image("raycast(keys)", keys, keys_pitch, rows, cols, 4)) != 0)
+      return rc;
+    if (!(vol->z0 <= z_own0 && z_own0 < z_own1 && z_own1 <= vol->z1))
+      return fail(YAKHIP_EINVAL, "raycast_slab: own layers [%d, %d) must be a non-empty part of the held layers [%d, %d)",
+                  z_own0, z_own1, vol->z0, vol->z1);
+    const int h = raycast_halo_layers(vol, step_factor, gradient_delta_factor);
+    if (z_own0 - vol->z0 < (z_own0 < h ? z_own0 : h) || vol->z1 - z_own1 < (vol->dims[2] - z_own1 < h ? vol->dims[2] - z_own1 : h))
+      return fail(YAKHIP_EINVAL, "raycast_slab: own layers [%d, %d) of held [%d, %d) leave less than the %d halo layers needed",
+                  z_own0, z_own1, vol->z0, vol->z1, h);
+  }
 
   RaycastParams p;
   p.vol = (const uint32_t*)vol->data;
@@ -560,6 +586,8 @@ static int raycast_common(yakhip_ctx* ctx, const yakhip_volume* vol, const float
   p.points = (uint8_t*)points, p.normals = (uint8_t*)normals, p.depth = (uint8_t*)depth;
   p.points_pitch = (uint32_t)points_pitch, p.normals_pitch = (uint32_t)normals_pitch;
   p.depth_pitch = (uint32_t)depth_pitch;
+  p.keys = (uint8_t*)keys, p.keys_pitch = (uint32_t)keys_pitch;
+  p.z_base = vol->z0, p.z_held = vol->z1 - vol->z0, p.z_own0 = z_own0, p.z_own1 = z_own1;
   return launch_raycast(ctx, p);
 }
 
@@ -583,6 +611,76 @@ int yakhip_raycast_depth(yakhip_ctx* ctx, const yakhip_volume* vol, const float 
     return fail(YAKHIP_EINVAL, "raycast(depth): null image pointer");
   return raycast_common(ctx, vol, R, t, Rinv, intr, step_factor, gradient_delta_factor, nullptr, 0, depth_dev,
                         depth_pitch, normals_dev, normals_pitch, rows, cols);
+}
+
+int yakhip_raycast_halo(const yakhip_volume* vol, float step_factor, float gradient_delta_factor, int* layers)
+{
+  int rc = check_volume(vol);
+  if (rc != 0)
+    return rc;
+  if (!layers || !(vol->trunc_dist > 0.f) || !(step_factor > 0.f) || !(gradient_delta_factor > 0.f))
+    return fail(YAKHIP_EINVAL, "raycast_halo: null output or non-positive trunc_dist / factors");
+  *layers = raycast_halo_layers(vol, step_factor, gradient_delta_factor);
+  return 0;
+}
+
+int yakhip_raycast_slab(yakhip_ctx* ctx, const yakhip_volume* vol, int z_own0, int z_own1, const float R[9],
+                        const float t[3], const float Rinv[9], const float intr[4], float step_factor,
+                        float gradient_delta_factor, void* points_dev, size_t points_pitch, void* depth_dev,
+                        size_t depth_pitch, void* normals_dev, size_t normals_pitch, void* keys_dev, size_t keys_pitch,
+                        int rows, int cols)
+{
+  if (!keys_dev)
+    return fail(YAKHIP_EINVAL, "raycast_slab: null keys image");
+  return raycast_common(ctx, vol, R, t, Rinv, intr, step_factor, gradient_delta_factor, points_dev, points_pitch,
+                        depth_dev, depth_pitch, normals_dev, normals_pitch, rows, cols, keys_dev, keys_pitch, z_own0,
+                        z_own1);
+}
+
+int yakhip_raycast_resolve(yakhip_ctx* ctx, const yakhip_volume* vol, int z_own0, int z_own1, const float Rinv[9],
+                           float gradient_delta_factor, void* points_dev, size_t points_pitch, void* depth_dev,
+                           size_t depth_pitch, void* normals_dev, size_t normals_pitch, void* keys_dev, size_t keys_pitch,
+                           int rows, int cols)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_volume(vol)) != 0)
+    return rc;
+  if (!Rinv || !(gradient_delta_factor > 0.f))
+    return fail(YAKHIP_EINVAL, "raycast_resolve: null rotation or non-positive gradient delta factor");
+  if ((rc = check_image("raycast_resolve(normals)", normals_dev, normals_pitch, rows, cols, 16)) != 0)
+    return rc;
+  if ((rc = check_image("raycast_resolve(keys)", keys_dev, keys_pitch, rows, cols, 4)) != 0)
+    return rc;
+  if (points_dev && (rc = check_image("raycast_resolve(points)", points_dev, points_pitch, rows, cols, 16)) != 0)
+    return rc;
+  if (depth_dev && (rc = check_image("raycast_resolve(depth)", depth_dev, depth_pitch, rows, cols, 2)) != 0)
+    return rc;
+  if (!(vol->z0 <= z_own0 && z_own0 < z_own1 && z_own1 <= vol->z1))
+    return fail(YAKHIP_EINVAL, "raycast_resolve: own layers [%d, %d) must be a non-empty part of the held layers [%d, %d)",
+                z_own0, z_own1, vol->z0, vol->z1);
+  // the taps around a point of an own layer: ceil(delta / voxel) + 2 layers either way
+  const int h = (int)ceil((double)gradient_delta_factor) + 2;
+  if (z_own0 - vol->z0 < (z_own0 < h ? z_own0 : h) || vol->z1 - z_own1 < (vol->dims[2] - z_own1 < h ? vol->dims[2] - z_own1 : h))
+    return fail(YAKHIP_EINVAL, "raycast_resolve: own layers [%d, %d) of held [%d, %d) leave less than the %d halo layers needed",
+                z_own0, z_own1, vol->z0, vol->z1, h);
+
+  RaycastParams p;
+  memset(&p, 0, sizeof(p));
+  p.vol = (const uint32_t*)vol->data;
+  p.X = vol->dims[0], p.Y = vol->dims[1], p.Z = vol->dims[2];
+  p.vsx = vol->voxel_size[0], p.vsy = vol->voxel_size[1], p.vsz = vol->voxel_size[2];
+  p.ivx = 1.f / p.vsx, p.ivy = 1.f / p.vsy, p.ivz = 1.f / p.vsz;
+  p.gdx = p.vsx * gradient_delta_factor, p.gdy = p.vsy * gradient_delta_factor, p.gdz = p.vsz * gradient_delta_factor;
+  memcpy(p.Rinv, Rinv, sizeof(p.Rinv));
+  p.rows = rows, p.cols = cols;
+  p.points = (uint8_t*)points_dev, p.normals = (uint8_t*)normals_dev, p.depth = (uint8_t*)depth_dev;
+  p.points_pitch = (uint32_t)points_pitch, p.normals_pitch = (uint32_t)normals_pitch;
+  p.depth_pitch = (uint32_t)depth_pitch;
+  p.keys = (uint8_t*)keys_dev, p.keys_pitch = (uint32_t)keys_pitch;
+  p.z_base = vol->z0, p.z_held = vol->z1 - vol->z0, p.z_own0 = z_own0, p.z_own1 = z_own1;
+  return launch_raycast_resolve(ctx, p);
 }
 
 // ---- tracking side: depth pre-processing and ICP ----------------------------------------------
@@ -696,7 +794,39 @@ int yakhip_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], c
     return rc;
   return launch_icp_accumulate(ctx, R, t, intr, level, dist_thres, angle_thres, (const uint8_t*)vcurr_dev, vcurr_pitch,
                                (const uint8_t*)ncurr_dev, ncurr_pitch, (const uint8_t*)vprev_dev, vprev_pitch,
-                               (const uint8_t*)nprev_dev, nprev_pitch, rows, cols, sums_host, counts_host);
+                               (const uint8_t*)nprev_dev, nprev_pitch, rows, cols, sums_host, counts_host, 0, rows,
+                               nullptr);
+}
+
+int yakhip_icp_accumulate_rows(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], int level,
+                               float dist_thres, float angle_thres, const void* vcurr_dev, size_t vcurr_pitch,
+                               const void* ncurr_dev, size_t ncurr_pitch, const void* vprev_dev, size_t vprev_pitch,
+                               const void* nprev_dev, size_t nprev_pitch, int rows, int cols, int row_begin,
+                               int row_end, float* sums_dev)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!R || !t || !intr || !sums_dev)
+    return fail(YAKHIP_EINVAL, "icp_accumulate_rows: null pose, intrinsics or output");
+  if (((uintptr_t)sums_dev & 3) != 0)
+    return fail(YAKHIP_EALIGN, "icp_accumulate_rows: output not 4-byte aligned");
+  if (level < 0 || level > 15)
+    return fail(YAKHIP_EINVAL, "icp_accumulate_rows: pyramid level %d outside [0, 15]", level);
+  if ((rc = check_image("icp_accumulate_rows(vcurr)", vcurr_dev, vcurr_pitch, rows, cols, 16)) != 0)
+    return rc;
+  if ((rc = check_image("icp_accumulate_rows(ncurr)", ncurr_dev, ncurr_pitch, rows, cols, 16)) != 0)
+    return rc;
+  if ((rc = check_image("icp_accumulate_rows(vprev)", vprev_dev, vprev_pitch, rows, cols, 16)) != 0)
+    return rc;
+  if ((rc = check_image("icp_accumulate_rows(nprev)", nprev_dev, nprev_pitch, rows, cols, 16)) != 0)
+    return rc;
+  if (!(0 <= row_begin && row_begin <= row_end && row_end <= rows))
+    return fail(YAKHIP_EINVAL, "icp_accumulate_rows: rows [%d, %d) outside the image's %d", row_begin, row_end, rows);
+  return launch_icp_accumulate(ctx, R, t, intr, level, dist_thres, angle_thres, (const uint8_t*)vcurr_dev, vcurr_pitch,
+                               (const uint8_t*)ncurr_dev, ncurr_pitch, (const uint8_t*)vprev_dev, vprev_pitch,
+                               (const uint8_t*)nprev_dev, nprev_pitch, rows, cols, nullptr, nullptr, row_begin, row_end,
+                               sums_dev);
 }
 
 int yakhip_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], float dist_thres,
@@ -743,7 +873,7 @@ int yakhip_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], con
       if ((rc = launch_icp_accumulate(ctx, Rc, tc, intr, l, dist_thres, angle_thres, (const uint8_t*)L.vcurr,
                                       L.vcurr_pitch, (const uint8_t*)L.ncurr, L.ncurr_pitch, (const uint8_t*)L.vprev,
                                       L.vprev_pitch, (const uint8_t*)L.nprev, L.nprev_pitch, L.rows, L.cols, sums,
-                                      nullptr)) != 0)
+                                      nullptr, 0, L.rows, nullptr)) != 0)
         return rc;
       double A[36], b[6], r[6];
       int shift = 0;

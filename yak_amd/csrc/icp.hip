@@ -36,7 +36,8 @@ struct IcpParams
   float min_cosine, dist2_thres;
   const uint8_t *vcurr, *ncurr, *vprev, *nprev;
   uint32_t vcurr_pitch, ncurr_pitch, vprev_pitch, nprev_pitch;
-  int rows, cols;
+  int rows, cols;  // rows of the current maps to walk, starting at row0 (frows / fcols describe the whole image)
+  int row0;
 };
 
 __device__ __forceinline__ float4 f4_at(const uint8_t* base, uint32_t pitch, int y, int x)
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void icp_accumulate_kernel(const IcpParams p, 
     const int pix = base + i * 256;
     if (pix >= n_pixels)
       break;
-    const int y = pix / p.cols, x = pix - y * p.cols;
+    const int yr = pix / p.cols, x = pix - yr * p.cols, y = yr + p.row0;
 
     // find_coresp, proj_icp.cu:74-102
     int code = 0;
@@ -337,7 +338,8 @@ static int icp_scratch(yakhip_ctx* ctx, size_t need);
 int launch_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], int level,
                           float dist_thres, float angle_thres, const uint8_t* vcurr, size_t vcurr_pitch,
                           const uint8_t* ncurr, size_t ncurr_pitch, const uint8_t* vprev, size_t vprev_pitch,
-                          const uint8_t* nprev, size_t nprev_pitch, int rows, int cols, float sums[27], int counts[6])
+                          const uint8_t* nprev, size_t nprev_pitch, int rows, int cols, float sums[27], int counts[6],
+                          int row_begin, int row_end, float* sums_dev)
 {
   IcpParams p;
   p.state = nullptr;
@@ -353,11 +355,13 @@ int launch_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], c
   p.vcurr = vcurr, p.ncurr = ncurr, p.vprev = vprev, p.nprev = nprev;
   p.vcurr_pitch = (uint32_t)vcurr_pitch, p.ncurr_pitch = (uint32_t)ncurr_pitch;
   p.vprev_pitch = (uint32_t)vprev_pitch, p.nprev_pitch = (uint32_t)nprev_pitch;
-  p.rows = rows, p.cols = cols;
+  p.rows = row_end - row_begin, p.cols = cols, p.row0 = row_begin;
 
-  const long long n_pixels = (long long)rows * cols;
-  if (n_pixels > 0x7fffffffll - 2048)
+  const long long n_pixels = (long long)p.rows * cols;
+  if ((long long)rows * cols > 0x7fffffffll - 2048)
     return fail(YAKHIP_ERANGE, "icp: image too large");
+  if (n_pixels == 0)  // an empty row range (a rank with no rows of a coarse level): all sums are zero
+    return check(hipMemsetAsync(sums_dev, 0, kValues * sizeof(float), ctx->stream), "hipMemsetAsync");
   const int n_blocks = (int)((n_pixels + 256 * kPixelsPerLane - 1) / (256 * kPixelsPerLane));
 
   // context-owned scratch: block partials + the 33 results on the device, a pinned host mirror
@@ -369,8 +373,11 @@ int launch_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], c
   float* result = partial + (size_t)n_blocks * kValues;
   hipLaunchKernelGGL(icp_accumulate_kernel, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, p, partial, n_blocks);
   YAKHIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(icp_final_kernel, dim3(kValues), dim3(64), 0, ctx->stream, partial, n_blocks, result);
+  hipLaunchKernelGGL(icp_final_kernel, dim3(kValues), dim3(64), 0, ctx->stream, partial, n_blocks,
+                     sums_dev ? sums_dev : result);
   YAKHIP_TRY(hipGetLastError());
+  if (sums_dev)
+    return 0;  // rows variant: the 33 values stay on the device, nothing to wait for
   YAKHIP_TRY(hipMemcpyAsync(ctx->icp_pinned, result, kValues * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   YAKHIP_TRY(hipStreamSynchronize(ctx->stream));  // StreamHelper::get, projective_icp.cpp:44
   const float* h = (const float*)ctx->icp_pinned;
@@ -459,7 +466,7 @@ int launch_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], con
     p.vprev = (const uint8_t*)L.vprev, p.nprev = (const uint8_t*)L.nprev;
     p.vcurr_pitch = (uint32_t)L.vcurr_pitch, p.ncurr_pitch = (uint32_t)L.ncurr_pitch;
     p.vprev_pitch = (uint32_t)L.vprev_pitch, p.nprev_pitch = (uint32_t)L.nprev_pitch;
-    p.rows = L.rows, p.cols = L.cols;
+    p.rows = L.rows, p.cols = L.cols, p.row0 = 0;
     const int n_blocks = (int)(((long long)L.rows * L.cols + 256 * kPixelsPerLane - 1) / (256 * kPixelsPerLane));
     for (int it = 0; it < L.iterations; ++it)
     {

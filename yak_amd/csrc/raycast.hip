@@ -10,6 +10,20 @@
 //     and then examined in order -- the loop-carried dependency is the exit test only;
 //   * lanes that found a zero crossing leave the march and do the 64 trilinear taps together after it;
 //   * workgroup ids are remapped so each XCD (own L2) walks a contiguous band of the image.
+//
+// Slab mode (SLAB = true; SURVEY.md 8e option 1, no counterpart in the reference): the volume is cut in
+// z-slabs over several GPUs, every GPU holds its own layers plus a halo.  Each GPU marches ALL rays over
+// the same global sample sequence (the positions and march times are pure arithmetic, replayed without
+// fetches where the slab holds nothing) and examines the sample pairs whose first sample falls into a
+// layer it owns.  It reports the index k of the first pair that ends the march (zero crossing or the
+// - to + abort) with the hit's vertex and normal; the pair with the smallest k over all GPUs is the one
+// the whole-volume march stops at, so "min k wins" composites the slabs into the same image, bit for bit.
+// One case needs a second step: the secant refinement of a hit extrapolates when the trilinear values at
+// the two bracketing samples have the same sign, and the refined point can then lie any distance along the
+// ray, outside every halo.  The bracketing taps are always held, so the owner of the pair still computes
+// the point exactly; it stores the point (volume frame) in place of the normal and sets the key's low bit,
+// and after the composite the slab that owns the point's layer computes the normal there
+// (raycast_resolve_kernel) -- about 1 hit in 1500 on the orbit scene.
 #include "yakhip_internal.h"
 
 namespace yakhip
@@ -34,37 +48,58 @@ __device__ __forceinline__ float voxel_tsdf(const RaycastParams& p, int x, int y
   }
 }
 
+// Slab mode: z is a layer of the whole volume, p.vol starts at layer p.z_base and holds p.z_held layers.
+// A layer that is not held reads as 0 and clears `held`.
+template <bool IDX32, bool SLAB>
+__device__ __forceinline__ float voxel_tsdf_at(const RaycastParams& p, int x, int y, int z, bool& held)
+{
+  if constexpr (!SLAB)
+    return voxel_tsdf<IDX32>(p, x, y, z);
+  else
+  {
+    const int zl = z - p.z_base;
+    if ((unsigned)zl >= (unsigned)p.z_held)
+    {
+      held = false;
+      return 0.f;
+    }
+    return voxel_tsdf<IDX32>(p, x, y, zl);
+  }
+}
+
 __device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi); }
 
 // tsdf_volume.cu:209-217: nearest voxel, round-half-even.  The reference does not bounds-test here;
 // the clamp keeps the speculative look-ahead fetches inside the allocation and changes nothing where
-// the reference's read is defined.
-template <bool IDX32>
-__device__ __forceinline__ float fetch_tsdf(const RaycastParams& p, float px, float py, float pz)
+// the reference's read is defined.  Slab mode: `owned` = the sample's layer belongs to this slab.
+template <bool IDX32, bool SLAB>
+__device__ __forceinline__ float fetch_tsdf(const RaycastParams& p, float px, float py, float pz, bool& owned, bool& held)
 {
   const int x = clampi((int)__builtin_rintf(px * p.ivx), p.X - 1);
   const int y = clampi((int)__builtin_rintf(py * p.ivy), p.Y - 1);
   const int z = clampi((int)__builtin_rintf(pz * p.ivz), p.Z - 1);
-  return voxel_tsdf<IDX32>(p, x, y, z);
+  if constexpr (SLAB)
+    owned = z >= p.z_own0 && z < p.z_own1;
+  return voxel_tsdf_at<IDX32, SLAB>(p, x, y, z, held);
 }
 
 // tsdf_volume.cu:167-192: trilinear tap, argument in voxel units
-template <bool IDX32>
-__device__ float interpolate(const RaycastParams& p, float cfx, float cfy, float cfz)
+template <bool IDX32, bool SLAB>
+__device__ float interpolate(const RaycastParams& p, float cfx, float cfy, float cfz, bool& held)
 {
   const float fx = __builtin_floorf(cfx), fy = __builtin_floorf(cfy), fz = __builtin_floorf(cfz);
   if (!(fx >= 0.f && fx < (float)(p.X - 1) && fy >= 0.f && fy < (float)(p.Y - 1) && fz >= 0.f && fz < (float)(p.Z - 1)))
     return __builtin_nanf("");
   const int gx = (int)fx, gy = (int)fy, gz = (int)fz;
   const float a = cfx - (float)gx, b = cfy - (float)gy, c = cfz - (float)gz;
-  const float v000 = voxel_tsdf<IDX32>(p, gx + 0, gy + 0, gz + 0);
-  const float v001 = voxel_tsdf<IDX32>(p, gx + 0, gy + 0, gz + 1);
-  const float v010 = voxel_tsdf<IDX32>(p, gx + 0, gy + 1, gz + 0);
-  const float v011 = voxel_tsdf<IDX32>(p, gx + 0, gy + 1, gz + 1);
-  const float v100 = voxel_tsdf<IDX32>(p, gx + 1, gy + 0, gz + 0);
-  const float v101 = voxel_tsdf<IDX32>(p, gx + 1, gy + 0, gz + 1);
-  const float v110 = voxel_tsdf<IDX32>(p, gx + 1, gy + 1, gz + 0);
-  const float v111 = voxel_tsdf<IDX32>(p, gx + 1, gy + 1, gz + 1);
+  const float v000 = voxel_tsdf_at<IDX32, SLAB>(p, gx + 0, gy + 0, gz + 0, held);
+  const float v001 = voxel_tsdf_at<IDX32, SLAB>(p, gx + 0, gy + 0, gz + 1, held);
+  const float v010 = voxel_tsdf_at<IDX32, SLAB>(p, gx + 0, gy + 1, gz + 0, held);
+  const float v011 = voxel_tsdf_at<IDX32, SLAB>(p, gx + 0, gy + 1, gz + 1, held);
+  const float v100 = voxel_tsdf_at<IDX32, SLAB>(p, gx + 1, gy + 0, gz + 0, held);
+  const float v101 = voxel_tsdf_at<IDX32, SLAB>(p, gx + 1, gy + 0, gz + 1, held);
+  const float v110 = voxel_tsdf_at<IDX32, SLAB>(p, gx + 1, gy + 1, gz + 0, held);
+  const float v111 = voxel_tsdf_at<IDX32, SLAB>(p, gx + 1, gy + 1, gz + 1, held);
   float tsdf = 0.f;
   tsdf += v000 * (1.f - a) * (1.f - b) * (1.f - c);
   tsdf += v001 * (1.f - a) * (1.f - b) * c;
@@ -86,7 +121,24 @@ __device__ __forceinline__ void normalize3(float& x, float& y, float& z)
   z *= s;
 }
 
-template <bool IDX32>
+// compute_normal, tsdf_volume.cu:354-372 (before the rotation into the camera frame)
+template <bool IDX32, bool SLAB>
+__device__ __forceinline__ void surface_gradient(const RaycastParams& p, float px, float py, float pz, float& gx, float& gy,
+                                                 float& gz, bool& held)
+{
+  const float Fx1 = interpolate<IDX32, SLAB>(p, (px + p.gdx) * p.ivx, py * p.ivy, pz * p.ivz, held);
+  const float Fx2 = interpolate<IDX32, SLAB>(p, (px - p.gdx) * p.ivx, py * p.ivy, pz * p.ivz, held);
+  const float Fy1 = interpolate<IDX32, SLAB>(p, px * p.ivx, (py + p.gdy) * p.ivy, pz * p.ivz, held);
+  const float Fy2 = interpolate<IDX32, SLAB>(p, px * p.ivx, (py - p.gdy) * p.ivy, pz * p.ivz, held);
+  const float Fz1 = interpolate<IDX32, SLAB>(p, px * p.ivx, py * p.ivy, (pz + p.gdz) * p.ivz, held);
+  const float Fz2 = interpolate<IDX32, SLAB>(p, px * p.ivx, py * p.ivy, (pz - p.gdz) * p.ivz, held);
+  gx = (Fx1 - Fx2) / p.gdx;
+  gy = (Fy1 - Fy2) / p.gdy;
+  gz = (Fz1 - Fz2) / p.gdz;
+  normalize3(gx, gy, gz);
+}
+
+template <bool IDX32, bool SLAB>
 __global__ __launch_bounds__(256) void raycast_kernel(const RaycastParams p, int tiles_x, int n_tiles, int per_xcd)
 {
   // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; give each XCD a
@@ -132,13 +184,17 @@ __global__ __launch_bounds__(256) void raycast_kernel(const RaycastParams p, int
   float tcurr = tmin;
   float hcx = 0.f, hcy = 0.f, hcz = 0.f, hnx = 0.f, hny = 0.f, hnz = 0.f;  // the bracketing samples of a hit
 
-  // tsdf_volume.cu:320-351, kUnroll samples in flight per trip
+  // tsdf_volume.cu:320-351, kUnroll samples in flight per trip.  Slab mode: a pair is examined only if
+  // its first sample lies in an owned layer; `pair` counts the pairs of the global march.
+  int pair = 0;
   if (state == 0)
   {
-    float tsdf_next = fetch_tsdf<IDX32>(p, nx, ny, nz);
+    bool own_next = true, scratch = true;
+    float tsdf_next = fetch_tsdf<IDX32, SLAB>(p, nx, ny, nz, own_next, scratch);
     while (state == 0)
     {
       float qx[kUnroll], qy[kUnroll], qz[kUnroll], f[kUnroll];
+      bool own[kUnroll], held[kUnroll];
       float ax = nx, ay = ny, az = nz;
 #pragma unroll
       for (int k = 0; k < kUnroll; ++k)
@@ -147,9 +203,11 @@ __global__ __launch_bounds__(256) void raycast_kernel(const RaycastParams p, int
         ay += sy;
         az += sz;
         qx[k] = ax, qy[k] = ay, qz[k] = az;
-        f[k] = fetch_tsdf<IDX32>(p, ax, ay, az);
+        own[k] = true, held[k] = true;
+        f[k] = fetch_tsdf<IDX32, SLAB>(p, ax, ay, az, own[k], held[k]);
       }
       float cx = nx, cy = ny, cz = nz, fc = tsdf_next;
+      bool own_c = own_next;
 #pragma unroll
       for (int k = 0; k < kUnroll; ++k)
       {
@@ -157,58 +215,58 @@ __global__ __launch_bounds__(256) void raycast_kernel(const RaycastParams p, int
         {
           if (!(tcurr < tmax))
             state = 2;
-          else if (fc < 0.f && f[k] > 0.f)
-            state = 2;
-          else if (fc > 0.f && f[k] < 0.f)
+          else if (own_c && fc < 0.f && f[k] > 0.f)
+            state = 3;
+          else if (own_c && fc > 0.f && f[k] < 0.f)
           {
             state = 1;
             hcx = cx, hcy = cy, hcz = cz;
             hnx = qx[k], hny = qy[k], hnz = qz[k];
           }
           else
+          {
             tcurr += ts;
+            ++pair;
+          }
         }
-        cx = qx[k], cy = qy[k], cz = qz[k], fc = f[k];
+        cx = qx[k], cy = qy[k], cz = qz[k], fc = f[k], own_c = own[k];
       }
-      nx = cx, ny = cy, nz = cz, tsdf_next = fc;
+      nx = cx, ny = cy, nz = cz, tsdf_next = fc, own_next = own_c;
     }
   }
 
   const float qnan = __builtin_nanf("");
   float vx = qnan, vy = qnan, vz = qnan, vw = qnan, n0 = qnan, n1 = qnan, n2 = qnan, n3 = qnan;
-  bool hit = false;
+  bool hit = false, deferred = false;
   if (state == 1)
   {
     // tsdf_volume.cu:333-348
-    const float Ft = interpolate<IDX32>(p, hcx * p.ivx, hcy * p.ivy, hcz * p.ivz);
-    const float Ftdt = interpolate<IDX32>(p, hnx * p.ivx, hny * p.ivy, hnz * p.ivz);
+    bool held_bracket = true, held_normal = true;
+    const float Ft = interpolate<IDX32, SLAB>(p, hcx * p.ivx, hcy * p.ivy, hcz * p.ivz, held_bracket);
+    const float Ftdt = interpolate<IDX32, SLAB>(p, hnx * p.ivx, hny * p.ivy, hnz * p.ivz, held_bracket);
     const float Ts = tcurr - (ts * Ft) / (Ftdt - Ft);
     const float px = ox + dx * Ts, py = oy + dy * Ts, pz = oz + dz * Ts;
-
-    // compute_normal, tsdf_volume.cu:354-372
-    const float Fx1 = interpolate<IDX32>(p, (px + p.gdx) * p.ivx, py * p.ivy, pz * p.ivz);
-    const float Fx2 = interpolate<IDX32>(p, (px - p.gdx) * p.ivx, py * p.ivy, pz * p.ivz);
-    const float Fy1 = interpolate<IDX32>(p, px * p.ivx, (py + p.gdy) * p.ivy, pz * p.ivz);
-    const float Fy2 = interpolate<IDX32>(p, px * p.ivx, (py - p.gdy) * p.ivy, pz * p.ivz);
-    const float Fz1 = interpolate<IDX32>(p, px * p.ivx, py * p.ivy, (pz + p.gdz) * p.ivz);
-    const float Fz2 = interpolate<IDX32>(p, px * p.ivx, py * p.ivy, (pz - p.gdz) * p.ivz);
-    float gx = (Fx1 - Fx2) / p.gdx;
-    float gy = (Fy1 - Fy2) / p.gdy;
-    float gz = (Fz1 - Fz2) / p.gdz;
-    normalize3(gx, gy, gz);
+    float gx, gy, gz;
+    surface_gradient<IDX32, SLAB>(p, px, py, pz, gx, gy, gz, held_normal);
     const float prod = gx * gy * gz;
-    if (!(prod != prod))
+    deferred = SLAB && !held_normal;
+    if (deferred || !(prod != prod))
     {
       hit = true;
-      n0 = dot3(p.Rinv[0], p.Rinv[1], p.Rinv[2], gx, gy, gz);
-      n1 = dot3(p.Rinv[3], p.Rinv[4], p.Rinv[5], gx, gy, gz);
-      n2 = dot3(p.Rinv[6], p.Rinv[7], p.Rinv[8], gx, gy, gz);
-      n3 = 0.f;
       const float wx = px - p.t[0], wy = py - p.t[1], wz = pz - p.t[2];
       vx = dot3(p.Rinv[0], p.Rinv[1], p.Rinv[2], wx, wy, wz);
       vy = dot3(p.Rinv[3], p.Rinv[4], p.Rinv[5], wx, wy, wz);
       vz = dot3(p.Rinv[6], p.Rinv[7], p.Rinv[8], wx, wy, wz);
       vw = 0.f;
+      if (deferred)
+        n0 = px, n1 = py, n2 = pz;  // the point itself, for the slab that holds its surroundings
+      else
+      {
+        n0 = dot3(p.Rinv[0], p.Rinv[1], p.Rinv[2], gx, gy, gz);
+        n1 = dot3(p.Rinv[3], p.Rinv[4], p.Rinv[5], gx, gy, gz);
+        n2 = dot3(p.Rinv[6], p.Rinv[7], p.Rinv[8], gx, gy, gz);
+      }
+      n3 = 0.f;
     }
   }
 
@@ -231,8 +289,69 @@ __global__ __launch_bounds__(256) void raycast_kernel(const RaycastParams p, int
     unsigned short* drow = (unsigned short*)(p.depth + (size_t)y * p.depth_pitch);
     drow[x] = mm_out;
   }
+  if constexpr (SLAB)
+  {
+    // the pair that ended the march here (zero crossing = 1, abort = 3), or "none": 2 * k + (1 if the
+    // normal is still to be computed where the refined point lies)
+    int* krow = (int*)(p.keys + (size_t)y * p.keys_pitch);
+    krow[x] = (state == 1 || state == 3) ? 2 * pair + (deferred ? 1 : 0) : 0x7fffffff;
+  }
+}
+
+// Slab mode, after the composite: the pixels whose key is odd hold a refined point (volume frame, in the
+// normals image) instead of a normal.  The slab that owns the point's layer computes the normal as the
+// whole-volume kernel would have (tsdf_volume.cu:340-348: a NaN normal discards the hit), writes it and
+// clears the key's low bit; the other slabs leave the pixel alone.
+template <bool IDX32>
+__global__ __launch_bounds__(256) void raycast_resolve_kernel(const RaycastParams p)
+{
+  const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if (x >= p.cols || y >= p.rows)
+    return;
+  int* krow = (int*)(p.keys + (size_t)y * p.keys_pitch);
+  const int key = krow[x];
+  if (key == 0x7fffffff || (key & 1) == 0)
+    return;
+  float4* nrow = (float4*)(p.normals + (size_t)y * p.normals_pitch);
+  const float4 q = nrow[x];
+  // the layer the point lies in, clamped; a point at infinity or NaN reads nothing (every tap is out of
+  // bounds) and goes to the slab of layer 0 resp. Z - 1
+  const float lz = __builtin_floorf(q.z * p.ivz);
+  const int zp = !(lz >= 0.f) ? 0 : (lz >= (float)(p.Z - 1) ? p.Z - 1 : (int)lz);
+  if (zp < p.z_own0 || zp >= p.z_own1)
+    return;
+  float gx, gy, gz;
+  bool held = true;
+  surface_gradient<IDX32, true>(p, q.x, q.y, q.z, gx, gy, gz, held);
+  const float prod = gx * gy * gz;
+  if (!(prod != prod))
+    nrow[x] = make_float4(dot3(p.Rinv[0], p.Rinv[1], p.Rinv[2], gx, gy, gz), dot3(p.Rinv[3], p.Rinv[4], p.Rinv[5], gx, gy, gz),
+                          dot3(p.Rinv[6], p.Rinv[7], p.Rinv[8], gx, gy, gz), 0.f);
+  else
+  {
+    const float qnan = __builtin_nanf("");
+    nrow[x] = make_float4(qnan, qnan, qnan, qnan);
+    if (p.points)
+      ((float4*)(p.points + (size_t)y * p.points_pitch))[x] = make_float4(qnan, qnan, qnan, qnan);
+    if (p.depth)
+      ((unsigned short*)(p.depth + (size_t)y * p.depth_pitch))[x] = 0;
+  }
+  krow[x] = key - 1;
 }
 }  // namespace
+
+int launch_raycast_resolve(yakhip_ctx* ctx, const RaycastParams& p)
+{
+  const dim3 grid((unsigned)((p.cols + 63) / 64), (unsigned)((p.rows + 3) / 4));
+  if (grid.y > 65535u)
+    return fail(YAKHIP_ERANGE, "raycast_resolve: image too tall");
+  const bool idx32 = (unsigned long long)p.X * (unsigned long long)p.Y * (unsigned long long)p.z_held <= (1ull << 30);
+  if (idx32)
+    hipLaunchKernelGGL((raycast_resolve_kernel<true>), grid, dim3(256), 0, ctx->stream, p);
+  else
+    hipLaunchKernelGGL((raycast_resolve_kernel<false>), grid, dim3(256), 0, ctx->stream, p);
+  return check(hipGetLastError(), "raycast_resolve_kernel launch");
+}
 
 int launch_raycast(yakhip_ctx* ctx, const RaycastParams& p)
 {
@@ -243,16 +362,22 @@ int launch_raycast(yakhip_ctx* ctx, const RaycastParams& p)
   const int n_tiles = (int)n_tiles_ll;
   const int per_xcd = (n_tiles + 7) / 8;
   const dim3 grid((unsigned)(per_xcd * 8));
-  const bool idx32 = (unsigned long long)p.X * (unsigned long long)p.Y * (unsigned long long)p.Z <= (1ull << 30);
+  const bool slab = p.keys != nullptr;
+  const bool idx32 =
+      (unsigned long long)p.X * (unsigned long long)p.Y * (unsigned long long)(slab ? p.z_held : p.Z) <= (1ull << 30);
 
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   int rc = timing_begin(ctx, &ev);
   if (rc != 0)
     return rc;
-  if (idx32)
-    hipLaunchKernelGGL((raycast_kernel<true>), grid, dim3(256), 0, ctx->stream, p, tiles_x, n_tiles, per_xcd);
+  if (slab && idx32)
+    hipLaunchKernelGGL((raycast_kernel<true, true>), grid, dim3(256), 0, ctx->stream, p, tiles_x, n_tiles, per_xcd);
+  else if (slab)
+    hipLaunchKernelGGL((raycast_kernel<false, true>), grid, dim3(256), 0, ctx->stream, p, tiles_x, n_tiles, per_xcd);
+  else if (idx32)
+    hipLaunchKernelGGL((raycast_kernel<true, false>), grid, dim3(256), 0, ctx->stream, p, tiles_x, n_tiles, per_xcd);
   else
-    hipLaunchKernelGGL((raycast_kernel<false>), grid, dim3(256), 0, ctx->stream, p, tiles_x, n_tiles, per_xcd);
+    hipLaunchKernelGGL((raycast_kernel<false, false>), grid, dim3(256), 0, ctx->stream, p, tiles_x, n_tiles, per_xcd);
   if ((rc = timing_end(ctx, ev)) != 0)
     return rc;
   return check(hipGetLastError(), "raycast_kernel launch");

@@ -100,12 +100,18 @@ struct RaycastParams
   uint8_t* normals;     // float4 image
   uint8_t* depth;       // uint16 image or nullptr
   uint32_t points_pitch, normals_pitch, depth_pitch;
+  // slab mode (keys != nullptr): vol starts at layer z_base and holds z_held layers, of which the global
+  // layers [z_own0, z_own1) are this slab's own; keys = int32 image of march-ending pair indices
+  uint8_t* keys;
+  uint32_t keys_pitch;
+  int z_base, z_held, z_own0, z_own1;
 };
 
 int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p);
 // n_frames >= 1 frames applied in order to the same slab; thr / coarse / grp_* / z_chunk are filled here
 int launch_integrate_batch(yakhip_ctx* ctx, const IntegrateParams* frames, int n_frames);
 int launch_raycast(yakhip_ctx* ctx, const RaycastParams& p);
+int launch_raycast_resolve(yakhip_ctx* ctx, const RaycastParams& p);  // slab mode, after the composite
 int launch_clear(const yakhip_ctx* ctx, uint32_t* data, size_t n_voxels);
 int launch_selftest_division(yakhip_ctx* ctx, unsigned long long counts[4]);
 int launch_compute_dists(const yakhip_ctx* ctx, const uint8_t* depth, size_t depth_pitch, uint8_t* dists,
@@ -127,7 +133,9 @@ int launch_resize_points_normals(const yakhip_ctx* ctx, const uint8_t* points, s
 int launch_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], int level,
                           float dist_thres, float angle_thres, const uint8_t* vcurr, size_t vcurr_pitch,
                           const uint8_t* ncurr, size_t ncurr_pitch, const uint8_t* vprev, size_t vprev_pitch,
-                          const uint8_t* nprev, size_t nprev_pitch, int rows, int cols, float sums[27], int counts[6]);
+                          const uint8_t* nprev, size_t nprev_pitch, int rows, int cols, float sums[27], int counts[6],
+                          int row_begin, int row_end, float* sums_dev);
+// (rows [row_begin, row_end) of the current maps; sums_dev != nullptr: leave the 33 values there and do not wait)
 
 // mc.hip (blocking).  `vol` points at layer z0; `layers` voxel layers are present, so layers - 1 cube
 // layers are meshed.  Only counts when triangles == nullptr or the count exceeds `capacity`.

@@ -2,8 +2,10 @@
 
 integrate needs no data-path collective: every rank integrates layers [z0, z1) of the same frame and
 the slabs concatenate, in rank order, to the single-GPU volume bit for bit (the kernel replays the
-reference's float accumulation from z = 0).  torch.distributed is used only around the path: timing
-reduction for the benchmark and gathering slabs for downloadTSDF.
+reference's float accumulation from z = 0).  torch.distributed is used around that path (timing
+reduction for the benchmark, gathering slabs for downloadTSDF) and for the two steps of the tracking
+side that do exchange data: compositing the per-slab ray casts (composite_raycast) and adding the
+per-rank ICP sums (allreduce_icp_sums).
 """
 import numpy as np
 
@@ -52,3 +54,95 @@ def gather_volume(dist, slab, dims, dst=0):
     if rank != dst:
         return None
     return torch.cat([o[:n] for o, n in zip(out, sizes)])
+
+
+def held_range(z_layers, z0, z1, halo):
+    """Layers a rank must HOLD to ray-cast its own layers [z0, z1): the halo on either side, cut at the
+    volume's ends.  The halo layers are integrated redundantly (integrate is a per-voxel function of the
+    frame), never exchanged."""
+    return max(0, int(z0) - int(halo)), min(int(z_layers), int(z1) + int(halo))
+
+
+KEY_NONE = 0x7FFFFFFF
+
+
+def _as_bits(img):
+    import torch
+
+    return img.view(torch.int32) if img.dtype == torch.float32 else img.to(torch.int32)
+
+
+def _from_bits(bits, like):
+    import torch
+
+    return bits.view(torch.float32) if like.dtype == torch.float32 else bits.to(like.dtype)
+
+
+def composite_raycast(dist, keys, images, fill, resolve=None):
+    """Per-slab ray casts -> the whole-volume image (SURVEY.md 8e option 1), on every rank.
+
+    keys: int32 tensor (rows, cols) from yakhip_raycast_slab; images: the payload tensors it wrote
+    (float32 (rows, cols, 4) points / normals, int16 (rows, cols) depth); fill: what a pixel without any
+    march-ending pair holds, per image (NaN for the maps, 0 for depth).  The slab with the smallest key
+    owns the pixel; keys of different slabs never tie.  Two collectives: MIN over the keys, then a SUM of
+    the payload bit patterns with every non-winner zeroed (one non-zero term: exact).
+
+    resolve(keys, images): the rank's yakhip_raycast_resolve on the composited tensors, in place.  It is
+    called when some winning key is odd (a hit whose normal has to be computed by the slab that holds the
+    refined point); the pixels concerned -- the same list on every rank -- are then composited once more.
+    Returns (composited images, best keys, number of pixels still unresolved: 0 unless resolve is None)."""
+    import torch
+
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    best = keys.clone()
+    if world > 1:
+        dist.all_reduce(best, op=dist.ReduceOp.MIN)
+    mine = (keys == best) & (best != KEY_NONE)
+    none = best == KEY_NONE
+    out = []
+    for img, f in zip(images, fill):
+        bits = _as_bits(img)
+        m = mine if bits.dim() == 2 else mine.unsqueeze(-1)
+        bits = torch.where(m, bits, torch.zeros_like(bits))
+        if world > 1:
+            dist.all_reduce(bits, op=dist.ReduceOp.SUM)
+        res = _from_bits(bits, img)
+        n = none if res.dim() == 2 else none.unsqueeze(-1)
+        out.append(torch.where(n, torch.full_like(res, f), res).contiguous())
+
+    odd = (best != KEY_NONE) & ((best & 1) == 1)
+    idx = odd.reshape(-1).nonzero().squeeze(1)  # the same pixels on every rank
+    if idx.numel() == 0 or resolve is None:
+        return out, best, int(idx.numel())
+    keys2 = best.clone()
+    resolve(keys2, out)
+    k2 = keys2.reshape(-1)[idx]
+    b2 = k2.clone()
+    if world > 1:
+        dist.all_reduce(b2, op=dist.ReduceOp.MIN)
+    done = (b2 & 1) == 0
+    mine2 = (k2 == b2) & done
+    n_pix = best.numel()
+    for o in out:
+        flat = o.reshape(n_pix, -1)
+        old = _as_bits(flat[idx])
+        bits = torch.where(mine2.unsqueeze(-1), old, torch.zeros_like(old))
+        if world > 1:
+            dist.all_reduce(bits, op=dist.ReduceOp.SUM)
+        flat[idx] = _from_bits(torch.where(done.unsqueeze(-1), bits, old), o)
+    best.reshape(-1)[idx] = b2
+    return out, best, int((~done).sum().item())
+
+
+def row_range(rows, world, rank):
+    """Image rows [r0, r1) of one pyramid level that `rank` accumulates ICP sums over."""
+    return slab_range(rows, world, rank)
+
+
+def allreduce_icp_sums(dist, sums33):
+    """Adds the 33 per-rank values of yakhip_icp_accumulate_rows over the ranks, in place (float32 tensor
+    on the rank's device): every rank then holds the sums of the whole image and solves the same 6 x 6
+    system.  19 collectives of 132 bytes per frame: latency-bound."""
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(sums33, op=dist.ReduceOp.SUM)
+    return sums33
