@@ -307,8 +307,9 @@ int yakhip_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], con
  * of the whole volume.  BLOCKING.  *n_triangles_host always receives the number of triangles the
  * slab produces; they are written only if triangles_dev != NULL and capacity_triangles is large enough
  * -- call once with NULL to size the buffer, or pass a generous one and compare.
- * The triangle SET equals the CPU routine's; the order is this library's (deterministic: by tile, z,
- * x, case-table order), the reference's being nondeterministic (OpenMP critical section, :163-171).
+ * The triangle SET equals the CPU routine's; the order is this library's (deterministic: by 63 x 4 x 8
+ * cube tile, then z, row, x within the tile, then case-table order), the reference's being
+ * nondeterministic (OpenMP critical section, :163-171).
  * Multi-GPU: give each rank's slab one extra layer of overlap (z1 = next slab's z0 + 1) and the
  * per-rank sets are disjoint and complete.  No vertex merging here (MarchingCubesParameters::clean is
  * VTK's vtkCleanPolyData in the reference, :204-216; the host layer does it). */
