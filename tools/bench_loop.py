@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Fused frames per second of the complete KinFu loop (reference yak/src/kfusion/kinfu.cpp:162-309) at
 512^3 on the S2 orbit, driven through the C ABI exactly as yak_amd/host/kinfu.cpp drives it:
-compute_dists, bilateral, pyramid, point/normal maps, ICP (10/5/4 iterations on levels 2/1/0, 6x6 solve
-on the host), integrate, raycast, 2x2 resize.  GPU only; no oracle.  Prints per-stage device times.
+compute_dists, bilateral, pyramid, point/normal maps, ICP (10/5/4 iterations on levels 0/1/2 as
+projective_icp.cpp:206 indexes iters_ by level; coarse to fine), integrate, raycast, 2x2 resize.  GPU only; no oracle.  Prints per-stage device times.
 
   python tools/bench_loop.py [--n 512] [--frames 60] [--no-icp]
 """
@@ -45,7 +45,7 @@ def main():
     ctx.clear_volume(desc)
     i16 = lambda r, c: torch.empty((r, c), dtype=torch.int16, device="cuda")        # noqa: E731
     f4 = lambda r, c: torch.empty((r, c, 4), dtype=torch.float32, device="cuda")    # noqa: E731
-    LEVELS, iters = 3, (10, 5, 4)  # iterations on levels 2, 1, 0 (coarse to fine)
+    LEVELS, iters = 3, (10, 5, 4)  # iterations on levels 0, 1, 2 (iters_[level_index], projective_icp.cpp:206)
     dists = i16(rows, cols)
     cur_d = [i16(rows >> l, cols >> l) for l in range(LEVELS)]
     cur_p = [f4(rows >> l, cols >> l) for l in range(LEVELS)]
@@ -85,7 +85,7 @@ def main():
                 R, t = np.eye(3), np.zeros(3)      # current -> previous camera
                 for l in reversed(range(LEVELS)):
                     r_, c_ = rows >> l, cols >> l
-                    for _ in range(iters[LEVELS - 1 - l]):
+                    for _ in range(iters[l]):
                         sums, _ = ctx.icp_accumulate(np.float32(R).reshape(-1), np.float32(t), intr, l, 0.1,
                                                      math.radians(30.0), cur_p[l].data_ptr(), c_ * 16, cur_n[l].data_ptr(),
                                                      c_ * 16, prv_p[l].data_ptr(), c_ * 16, prv_n[l].data_ptr(), c_ * 16,
@@ -103,7 +103,7 @@ def main():
                         R, t = Ri @ R, Ri @ t + x[3:]
             else:
                 lv = [(cur_p[l].data_ptr(), cur_n[l].data_ptr(), prv_p[l].data_ptr(), prv_n[l].data_ptr(), (cols >> l) * 16,
-                       rows >> l, cols >> l, iters[::-1][l]) for l in range(LEVELS)]
+                       rows >> l, cols >> l, iters[l]) for l in range(LEVELS)]
                 Rl, tl, ok = ctx.icp_estimate(np.eye(3).reshape(-1), np.zeros(3), intr, 0.1, math.radians(30.0), lv)
                 assert ok
                 R, t = np.array(Rl, dtype=np.float64).reshape(3, 3), np.array(tl, dtype=np.float64)

@@ -78,7 +78,7 @@ def _from_bits(bits, like):
     return bits.view(torch.float32) if like.dtype == torch.float32 else bits.to(like.dtype)
 
 
-def composite_raycast(dist, keys, images, fill, resolve=None):
+def composite_raycast(dist, keys, images, fill, resolve=None, all_reduce=None):
     """Per-slab ray casts -> the whole-volume image (SURVEY.md 8e option 1), on every rank.
 
     keys: int32 tensor (rows, cols) from yakhip_raycast_slab; images: the payload tensors it wrote
@@ -90,13 +90,19 @@ def composite_raycast(dist, keys, images, fill, resolve=None):
     resolve(keys, images): the rank's yakhip_raycast_resolve on the composited tensors, in place.  It is
     called when some winning key is odd (a hit whose normal has to be computed by the slab that holds the
     refined point); the pixels concerned -- the same list on every rank -- are then composited once more.
+    all_reduce(dist, tensor, "sum" | "min"): replaces dist.all_reduce (e.g. to stage device tensors through
+    the host for a CPU-only backend).
     Returns (composited images, best keys, number of pixels still unresolved: 0 unless resolve is None)."""
     import torch
 
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    if all_reduce is None:
+        def all_reduce(d, tensor, op):
+            d.all_reduce(tensor, op=d.ReduceOp.SUM if op == "sum" else d.ReduceOp.MIN)
+            return tensor
     best = keys.clone()
     if world > 1:
-        dist.all_reduce(best, op=dist.ReduceOp.MIN)
+        all_reduce(dist, best, "min")
     mine = (keys == best) & (best != KEY_NONE)
     none = best == KEY_NONE
     out = []
@@ -105,7 +111,7 @@ def composite_raycast(dist, keys, images, fill, resolve=None):
         m = mine if bits.dim() == 2 else mine.unsqueeze(-1)
         bits = torch.where(m, bits, torch.zeros_like(bits))
         if world > 1:
-            dist.all_reduce(bits, op=dist.ReduceOp.SUM)
+            all_reduce(dist, bits, "sum")
         res = _from_bits(bits, img)
         n = none if res.dim() == 2 else none.unsqueeze(-1)
         out.append(torch.where(n, torch.full_like(res, f), res).contiguous())
@@ -119,7 +125,7 @@ def composite_raycast(dist, keys, images, fill, resolve=None):
     k2 = keys2.reshape(-1)[idx]
     b2 = k2.clone()
     if world > 1:
-        dist.all_reduce(b2, op=dist.ReduceOp.MIN)
+        all_reduce(dist, b2, "min")
     done = (b2 & 1) == 0
     mine2 = (k2 == b2) & done
     n_pix = best.numel()
@@ -128,7 +134,7 @@ def composite_raycast(dist, keys, images, fill, resolve=None):
         old = _as_bits(flat[idx])
         bits = torch.where(mine2.unsqueeze(-1), old, torch.zeros_like(old))
         if world > 1:
-            dist.all_reduce(bits, op=dist.ReduceOp.SUM)
+            all_reduce(dist, bits, "sum")
         flat[idx] = _from_bits(torch.where(done.unsqueeze(-1), bits, old), o)
     best.reshape(-1)[idx] = b2
     return out, best, int((~done).sum().item())
