@@ -38,3 +38,22 @@ def test_frontend_library_exports_reference_class_names():
 @pytest.mark.gpu
 def test_host_layer_gpu_fusion_server_matches_oracle():
     run("--gpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [[], ["--track"]])
+def test_offline_fuse_example(tmp_path, mode):
+    """examples/offline_fuse: FusionServer::fuse with supplied poses (what yak_ros does) or KinFu tracking from
+    depth alone, then downloadTSDF -> marchingCubesCPU -> PLY."""
+    exe = os.path.join(ROOT, "examples", "offline_fuse")
+    assert os.path.exists(exe), "examples/offline_fuse missing: run __graft_entry__.build()"
+    ply = str(tmp_path / "mesh.ply")
+    r = subprocess.run([exe, "--n", "96", "--frames", "10", "--ply", ply] + mode, capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stderr[-2000:]
+    head = open(ply).read(400).split("\n")
+    n_vert, n_face = int(head[2].split()[-1]), int(head[6].split()[-1])
+    assert n_vert > 1000 and n_face > 2000
+    if mode:
+        worst = float(r.stdout.split("true orbit:")[1].split("mm")[0])
+        assert worst < 0.5 * 3000.0 / 96                                         # half a voxel

@@ -214,6 +214,20 @@ class Context:
             d.intr[:] = [float(v) for v in intr]
         _chk(load().yakhip_integrate_batch(self._h, C.byref(vol), arr, len(frames)))
 
+    # ---- host <-> device copies (blocking; the reference's DeviceMemory[2D]::upload / download) ----
+    def upload(self, dst_ptr, src, nbytes):
+        _chk(load().yakhip_upload(self._h, C.c_void_p(dst_ptr), C.c_void_p(src), nbytes))
+
+    def download(self, dst, src_ptr, nbytes):
+        _chk(load().yakhip_download(self._h, C.c_void_p(dst), C.c_void_p(src_ptr), nbytes))
+
+    def upload_2d(self, dst_ptr, dst_pitch, src, src_pitch, width_bytes, rows):
+        _chk(load().yakhip_upload_2d(self._h, C.c_void_p(dst_ptr), dst_pitch, C.c_void_p(src), src_pitch, width_bytes, rows))
+
+    def download_2d(self, dst, dst_pitch, src_ptr, src_pitch, width_bytes, rows):
+        _chk(load().yakhip_download_2d(self._h, C.c_void_p(dst), dst_pitch, C.c_void_p(src_ptr), src_pitch, width_bytes,
+                                       rows))
+
     def raycast_points(self, vol, R, t, Rinv, intr, points_ptr, points_pitch, normals_ptr, normals_pitch, rows, cols,
                        step_factor=0.75, gradient_delta_factor=0.5):
         _chk(load().yakhip_raycast_points(self._h, C.byref(vol), _f32(R, 9), _f32(t, 3), _f32(Rinv, 9), _f32(intr, 4),

@@ -29,6 +29,8 @@ struct yakhip_ctx
   void* mc_scratch;    // marching cubes: tile counts, tile offsets, total (device)
   size_t mc_scratch_bytes;
   void* mc_pinned;     // marching cubes: pinned host copy of the total
+  void* stage[2];      // host <-> device copies: two pinned staging buffers and the events that free them
+  hipEvent_t stage_done[2];
   int kernel_timing;   // record a hipEvent pair around every integrate_kernel launch
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_events;
   size_t timing_used;
