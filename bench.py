@@ -161,6 +161,23 @@ def next_rows(ctx, torch, capi, synth, with_cpu):
     return out
 
 
+def kinfu_loop_row(ctx):
+    """BASELINE metric part 3: fused frames per second of the full loop (integrate + raycast + projective ICP)
+    at 512^3 on the S2 orbit, tracking from depth alone; and with supplied poses."""
+    from yak_amd.loop import run_kinfu_loop
+
+    run_kinfu_loop(ctx, VOXELS_PER_RANK_EDGE, 8, "device")  # warm-up: allocations, first launches
+    r = run_kinfu_loop(ctx, VOXELS_PER_RANK_EDGE, 60, "device")
+    p = run_kinfu_loop(ctx, VOXELS_PER_RANK_EDGE, 60, None)
+    return {"workload": "512^3, 60 frames of the S2 orbit (1.2 deg per frame, 1 mm depth noise), depth frames resident in HBM; "
+                        "per frame: compute_dists, bilateral, 3-level pyramid, point/normal maps, ICP 10/5/4 linearisations "
+                        "(device-resident loop), integrate, raycast, 2x2 resize; host waits once per frame",
+            "fused_frames_per_s": round(r["frames_per_s"], 1),
+            "fused_frames_per_s_supplied_poses": round(p["frames_per_s"], 1),
+            "worst_position_error_mm": round(r["worst_position_error_mm"], 2),
+            "stage_ms": {k: round(v, 4) for k, v in r["stage_ms"].items()}}
+
+
 def load_traffic(workload_key):
     """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/traffic.json), or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -187,6 +204,7 @@ def main():
     ap.add_argument("--no-nt", action="store_true", help="plain instead of non-temporal volume accesses (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rows", action="store_true", help="skip the secondary measurements (raycast, ICP, MC, batch)")
+    ap.add_argument("--no-loop", action="store_true", help="skip the full KinFu loop row (its single-frame integrate launches would enter a kernel-trace average of the headline kernel)")
     args = ap.parse_args()
 
     import torch
@@ -344,6 +362,11 @@ def main():
                 out["next_rows"] = next_rows(ctx, torch, capi, synth, not args.no_cpu_baseline)
             except Exception as e:  # secondary: never take the headline down with it
                 out["next_rows"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            if not args.no_loop:
+                try:
+                    out["kinfu_loop"] = kinfu_loop_row(ctx)
+                except Exception as e:
+                    out["kinfu_loop"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out), flush=True)
 
     if dist is not None:

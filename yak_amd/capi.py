@@ -152,13 +152,15 @@ class Context:
     that torch tensors, torch events and these kernels are ordered on the same queue."""
 
     def __init__(self, device=0, use_torch_stream=True):
+        if use_torch_stream:
+            # torch first: it ships its own HIP runtime, and a process that has already initialised another
+            # copy through libyakhip.so finds "no HIP GPUs" when torch initialises afterwards
+            import torch
         L = load()
         self._h = C.c_void_p()
         _chk(L.yakhip_ctx_create(C.byref(self._h), int(device)))
         self.device = int(device)
         if use_torch_stream:
-            import torch
-
             self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
     def close(self):
