@@ -136,6 +136,22 @@ def test_mc_tile_depth_option_does_not_change_the_set(gpu_ctx, depth):
     assert np.array_equal(canon(got), want)
 
 
+def test_mc_wide_slab_of_a_2048_volume(gpu_ctx):
+    """Config 5's shape in small: the first 24 layers of a 2048 x 512 x 2048 volume as one rank's slab (33
+    wave tiles per row, the last one partial; 25 M voxels), a tilted plane through it."""
+    X, Y, Z1 = 2048, 512, 24
+    x = np.arange(X, dtype=np.float32)[None, None, :]
+    y = np.arange(Y, dtype=np.float32)[None, :, None]
+    z = np.arange(Z1, dtype=np.float32)[:, None, None]
+    d = np.clip((z - 11.3 + 0.004 * x - 0.007 * y) / 3.0, -1, 1).astype(np.float16)
+    vol = (d.view(np.uint16).astype(np.uint32) | (5 << 16)).reshape(-1)
+    dev = torch.from_numpy(vol.view(np.int32)).cuda()
+    got = gpu_mc(gpu_ctx, dev, (X, Y, 2048), 4, 0.0014648, z0=0, z1=Z1)
+    want = oracle.marching_cubes(vol, (X, Y, Z1), 4, 0.0014648)      # the slab as a volume of its own
+    assert len(got) == len(want) > 1500000
+    assert np.array_equal(canon(got), canon(want))
+
+
 def test_mc_512_volume_fused_on_gpu(gpu_ctx):
     n = 512
     dims, vs, tr = synth.volume_geometry(n)
