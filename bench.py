@@ -204,6 +204,7 @@ def main():
     ap.add_argument("--no-nt", action="store_true", help="plain instead of non-temporal volume accesses (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rows", action="store_true", help="skip the secondary measurements (raycast, ICP, MC, batch)")
+    ap.add_argument("--as-rank", default="", metavar="W:R", help="diagnostic: time the slab of rank R of a W-GPU job on this one GPU")
     ap.add_argument("--no-loop", action="store_true", help="skip the full KinFu loop row (its single-frame integrate launches would enter a kernel-trace average of the headline kernel)")
     args = ap.parse_args()
 
@@ -214,6 +215,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    emulate = None
+    if args.as_rank:  # one GPU does the work of rank R of a W-rank job (same slab, same frame); no process group
+        emulate = tuple(int(v) for v in args.as_rank.split(":"))
+        args.gpus = world
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
@@ -228,6 +233,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- workload ---------------------------------------------------------------------------------
+    if emulate:
+        world, rank = emulate
     if world not in GLOBAL_DIMS:
         sys.exit("supported world sizes: %s" % sorted(GLOBAL_DIMS))
     dims = GLOBAL_DIMS[world]
@@ -325,7 +332,7 @@ def main():
     else:
         updated_total = updated
 
-    if rank == 0:
+    if rank == 0 or emulate:
         gvox = updated_total * args.steps / elapsed / 1e9
         # algorithmic bytes of ONE launch on ONE GPU: 4 B read + 4 B written per
         # updated voxel + one pass over the half ray-distance image
@@ -366,6 +373,9 @@ def main():
                                          "how": "torch in-place int32 add over the same slab (no arithmetic, same traffic)"},
             },
         }
+        if emulate:
+            out["config"]["emulated_rank"] = "%d of %d (this GPU's slab only: value is per GPU)" % (rank, world)
+            out["n_gpus"] = 1
         if world == 1 and not args.no_cpu_baseline:
             dists_host = d_dists.cpu().numpy().view(np.uint16)
             out["cpu_baseline"] = cpu_baseline(dims, vs, tr, dists_host, R, t, intr, synth.MAX_WEIGHT)

@@ -21,6 +21,14 @@ def test_host_layer_cpu_cases():
     run("--cpu")
 
 
+def test_closed_form_accumulation_equals_the_loop():
+    """yak_amd/csrc/ffwd.hpp (n rounded fp32 additions in O(binades crossed)) against the loop, 2.5 M cases."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_ffwd")
+    assert os.path.exists(exe), "tests/cpp/test_ffwd missing: run __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout[-3000:]
+
+
 def test_frontend_library_exports_reference_class_names():
     lib = os.path.join(ROOT, "yak_amd", "host", "libyak_frontend.so")
     assert os.path.exists(lib)

@@ -95,6 +95,19 @@ def test_batch_slabs_and_group_test_switch(gpu_ctx):
     assert np.array_equal(got, whole)
 
 
+def test_batch_deep_slab_uses_one_checkpoint_per_frame(gpu_ctx):
+    dims = (64, 48, 900)
+    vs, tr = (3.0 / 64, 3.0 / 48, 3.0 / 900), 0.04
+    frames = frames_s2([20, 110, 200, 290, 65])
+    z0, z1 = 700, 760
+    n = dims[0] * dims[1] * (z1 - z0)
+    want = np.zeros(n, dtype=np.uint32)
+    want = run_oracle(want, dims, vs, tr, synth.MAX_WEIGHT, frames, z0=z0, z1=z1)
+    assert (want != 0).sum() > 1000
+    got = run_batch(gpu_ctx, np.zeros(n, dtype=np.uint32), dims, vs, tr, synth.MAX_WEIGHT, frames, z0=z0, z1=z1)
+    assert np.array_equal(got, want)
+
+
 def test_batch_narrow_layouts_fall_back_frame_by_frame(gpu_ctx):
     frames = frames_s2([5, 95, 185])
     # X not a multiple of 4, and a 4-byte-aligned (not 16) base: the single-frame kernels take over

@@ -374,6 +374,30 @@ def test_integrate_slab_of_a_large_volume(gpu_ctx, n, z0, z1, tile):
     assert np.array_equal(got >> 16, want >> 16) and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("view,z0,z1", [(10, 64, 90), (100, 1500, 1530), (205, 700, 741), (290, 1940, 2000)])
+def test_integrate_deep_slab_starts_from_closed_form_column_positions(gpu_ctx, view, z0, z1):
+    """A slab at z0 >= 64 starts every column from the position checkpoint_kernel computes in closed form
+    (yak_amd/csrc/ffwd.hpp) instead of replaying z0 rounded additions: same voxels as the oracle, which
+    replays them one by one, and as the library with the shortcut switched off."""
+    dims = (48, 40, 2000)
+    vs, tr = (3.0 / 48, 3.0 / 40, 3.0 / 2000), 0.04
+    depth, R, t = synth.scene_s2(view, noise_mm=1.0)
+    dists = oracle.compute_dists(depth, synth.INTR)
+    start = np.zeros(dims[0] * dims[1] * (z1 - z0), dtype=np.uint32)
+    want = start.copy()
+    for _ in range(2):
+        oracle.integrate(want, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR, z0=z0, z1=z1, nthreads=8)
+    assert (want != 0).sum() > 1000
+    got = gpu_integrate(gpu_ctx, start, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR, z0=z0, z1=z1, frames=2)
+    assert np.array_equal(got, want)
+    gpu_ctx.set_option("checkpoint", 0)
+    try:
+        plain = gpu_integrate(gpu_ctx, start, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR, z0=z0, z1=z1, frames=2)
+    finally:
+        gpu_ctx.set_option("checkpoint", 1)
+    assert np.array_equal(plain, want)
+
+
 @pytest.mark.parametrize("tile", [3, 4, 5, 6])
 def test_integrate_wave_footprint_does_not_change_results(gpu_ctx, tile):
     # "tile" folds a wave into 2^tile lanes along x by 64 >> tile rows; volumes it does not divide

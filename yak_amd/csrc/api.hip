@@ -123,10 +123,13 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->force_vx = 0;
   ctx->zu = 0;
   ctx->group_test = 1;
+  ctx->checkpoint = 1;
   ctx->tile_shift = 0;
   ctx->mc_z_chunk = 0;
   ctx->thr = nullptr;
   ctx->thr_bytes = 0;
+  ctx->ckpt = nullptr;
+  ctx->ckpt_bytes = 0;
   ctx->icp_scratch = nullptr;
   ctx->icp_scratch_bytes = 0;
   ctx->icp_pinned = nullptr;
@@ -158,6 +161,8 @@ int yakhip_ctx_destroy(yakhip_ctx* ctx)
     rc = check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     if (ctx->thr)
       (void)hipFree(ctx->thr);
+    if (ctx->ckpt)
+      (void)hipFree(ctx->ckpt);
     if (ctx->icp_scratch)
       (void)hipFree(ctx->icp_scratch);
     if (ctx->icp_pinned)
@@ -242,6 +247,11 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
   if (strcmp(key, "group_test") == 0)
   {
     ctx->group_test = value != 0;
+    return 0;
+  }
+  if (strcmp(key, "checkpoint") == 0)
+  {
+    ctx->checkpoint = value != 0;
     return 0;
   }
   if (strcmp(key, "tile") == 0)

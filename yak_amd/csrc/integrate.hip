@@ -32,6 +32,9 @@
 
 #include "yakhip_internal.h"
 
+#define YAK_FFWD_FN __host__ __device__ inline
+#include "ffwd.hpp"
+
 namespace yakhip
 {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -624,8 +627,25 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
       A.z[k][h] = dot3(p.R[6], p.R[7], p.R[8], vxx, vxy, 0.f) + p.t[2];
     }
 
-  // Replay the additions the reference performed on layers [0, zs) (tsdf_volume.cu:76).
-  for (int i = 0; i < zs; ++i)
+  // Replay the additions the reference performed on layers [0, zs) (tsdf_volume.cu:76) -- from layer 0, or
+  // for a slab deep inside a tall volume from the column positions at z0 that checkpoint_kernel left.
+  int replay = zs;
+  if (p.ckpt)
+  {
+#pragma unroll
+    for (int k = 0; k < Pos<VX>::NP; ++k)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+      {
+        const int v = Pos<VX>::voxel(k, h);
+        const uint32_t col = elem + (uint32_t)(v < VX ? v : 0);
+        A.x[k][h] = p.ckpt[col];
+        A.y[k][h] = p.ckpt[p.plane + col];
+        A.z[k][h] = p.ckpt[2u * p.plane + col];
+      }
+    replay = zs - p.z0;
+  }
+  for (int i = 0; i < replay; ++i)
     advance<VX>(A, A, sx, sy, sz);
 
   const f32x2 fx2 = { p.fx, p.fx }, fy2 = { p.fy, p.fy }, cx2 = { p.cx, p.cx }, cy2 = { p.cy, p.cy };
@@ -680,6 +700,54 @@ static int launch_variant(yakhip_ctx* ctx, const IntegrateParams& p, dim3 grid)
   if ((rc = timing_end(ctx, ev)) != 0)
     return rc;
   return check(hipGetLastError(), "integrate_kernel launch");
+}
+
+// A slab that starts at layer z0 of a tall volume needs every column's camera-space position after the z0
+// rounded additions the reference performed below it.  Replaying them in the integrate kernel costs z0 steps
+// per chunk start -- for the last of 8 ranks of a 1024-layer volume more than the rank's own work, and all
+// workgroups do it at the same time, with the memory system idle.  Here they are done once per column and
+// frame, in closed form (ffwd.hpp: bit-identical to the loop), and the integrate kernels start from that.
+constexpr int kCheckpointFrom = 64;  // slabs starting below this layer replay from 0 as before
+
+__global__ __launch_bounds__(256) void checkpoint_kernel(const IntegrateParams p, float* out)
+{
+  const uint32_t col = blockIdx.x * 256u + threadIdx.x;
+  if (col >= p.plane)
+    return;
+  const int y = (int)(col / (uint32_t)p.X), x = (int)(col - (uint32_t)y * (uint32_t)p.X);
+  // tsdf_volume.cu:69, 71-72, exactly as integrate_kernel starts a column
+  const float vxx = (float)x * p.vsx, vxy = (float)y * p.vsy;
+  const float vx0 = dot3(p.R[0], p.R[1], p.R[2], vxx, vxy, 0.f) + p.t[0];
+  const float vy0 = dot3(p.R[3], p.R[4], p.R[5], vxx, vxy, 0.f) + p.t[1];
+  const float vz0 = dot3(p.R[6], p.R[7], p.R[8], vxx, vxy, 0.f) + p.t[2];
+  out[col] = yak_ffwd_accumulate(vx0, p.R[2] * p.vsz, p.z0);
+  out[p.plane + col] = yak_ffwd_accumulate(vy0, p.R[5] * p.vsz, p.z0);
+  out[2u * p.plane + col] = yak_ffwd_accumulate(vz0, p.R[8] * p.vsz, p.z0);
+}
+
+static int prepare_checkpoint(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slots)
+{
+  p.ckpt = nullptr;
+  if (p.z0 < kCheckpointFrom || !ctx->checkpoint)
+    return 0;
+  const size_t slot_bytes = ((size_t)p.plane * 3u * sizeof(float) + 255u) & ~(size_t)255u;
+  if (ctx->ckpt_bytes < slot_bytes * (size_t)slots)
+  {
+    if (ctx->ckpt)
+    {
+      YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
+      YAKHIP_TRY(hipFree(ctx->ckpt));
+      ctx->ckpt = nullptr;
+      ctx->ckpt_bytes = 0;
+    }
+    YAKHIP_TRY(hipMalloc(&ctx->ckpt, slot_bytes * (size_t)slots));
+    ctx->ckpt_bytes = slot_bytes * (size_t)slots;
+  }
+  float* out = (float*)((char*)ctx->ckpt + slot_bytes * (size_t)slot);
+  hipLaunchKernelGGL(checkpoint_kernel, dim3((p.plane + 255u) / 256u), dim3(256), 0, ctx->stream, p, out);
+  YAKHIP_TRY(hipGetLastError());
+  p.ckpt = out;
+  return 0;
 }
 
 // Per-frame set-up shared by the single-frame and the batched launch: the prepass kernel (band
@@ -750,7 +818,7 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
     p.grp_enable = ctx->group_test && p.fx > 0.f && p.fy > 0.f && p.cols < 32768 && p.rows < 32768 &&
                    std::isfinite(P) && std::isfinite(f) && coarse_bytes <= coarse_cap_bytes;
   }
-  return 0;
+  return prepare_checkpoint(ctx, p, slot, slots);
 }
 
 // z_chunk and grid for a plane of `blocks_x` workgroups.  Short chunks balance the load: the cost of a
@@ -769,7 +837,17 @@ static int choose_chunk(const yakhip_ctx* ctx, const IntegrateParams& p, uint32_
     chunk = (layers + 15) / 16;
     if (chunk < min_chunk)
       chunk = min_chunk;
-    while (chunk > 16 && (uint64_t)blocks_x * (uint64_t)((layers + chunk - 1) / chunk) < want_blocks)
+    // A chunk that starts at layer zs replays zs steps before its own `chunk` layers.  While the average
+    // replay stays below about 8 steps per layer of real work it hides behind the memory traffic (a whole
+    // 512-layer volume in 32-layer chunks: 256 / 32); a slab deep inside a tall volume needs longer chunks
+    // for that (measured, rank 7 of 8 at 1024^3, layers [896, 1024): 0.264 ms with 32-layer chunks).
+    const int for_replay = ((p.ckpt ? 0 : p.z0) + layers / 2) / 8;  // (with a checkpoint the replay starts at z0)
+    if (chunk < for_replay)
+    {
+      const int n = layers / for_replay > 1 ? layers / for_replay : 1;
+      chunk = (layers + n - 1) / n;
+    }
+    while (chunk > 16 && chunk > for_replay && (uint64_t)blocks_x * (uint64_t)((layers + chunk - 1) / chunk) < want_blocks)
       chunk = chunk / 2 < 16 ? 16 : chunk / 2;
   }
   if (chunk > layers)
@@ -903,7 +981,22 @@ __global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchPara
     // replay of the reference's per-layer additions on [0, zs), per frame (tsdf_volume.cu:69, 76)
     const float zx = f.R[2] * p.vsz, zy = f.R[5] * p.vsz, zz = f.R[8] * p.vsz;
     const f32x2 sx = { zx, zx }, sy = { zy, zy }, sz = { zz, zz };
-    for (int i = 0; i < zs; ++i)
+    int replay = zs;
+    if (f.ckpt)  // (all frames of a batch have one, or none: it depends on z0 only)
+    {
+#pragma unroll
+      for (int j = 0; j < Pos<VX>::NP; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+        {
+          const uint32_t col = elem + (uint32_t)Pos<VX>::voxel(j, h);
+          pos[k].x[j][h] = f.ckpt[col];
+          pos[k].y[j][h] = f.ckpt[p.plane + col];
+          pos[k].z[j][h] = f.ckpt[2u * p.plane + col];
+        }
+      replay = zs - p.z0;
+    }
+    for (int i = 0; i < replay; ++i)
       advance<VX>(pos[k], pos[k], sx, sy, sz);
   }
 

@@ -19,10 +19,13 @@ struct yakhip_ctx
   int force_vx;        // 0 = widest the layout allows; 1/2/4 caps the voxels per lane
   int zu;              // (unused; kept for option compatibility)
   int group_test;      // coarse group test on (default) / off
+  int checkpoint;      // deep slabs start from closed-form column positions (default) / replay from layer 0
   int tile_shift;      // 0 = default wave footprint, else 3..6 (tuning)
   int mc_z_chunk;      // 0 = default cube layers per marching-cubes tile (tuning)
   void* thr;           // scratch: per-pixel band thresholds of the frame being integrated
   size_t thr_bytes;
+  void* ckpt;          // scratch: column positions at layer z0 of a deep slab (integrate.hip, checkpoint_kernel)
+  size_t ckpt_bytes;
   void* icp_scratch;   // ICP: workgroup partials + the reduced 33 values (device)
   size_t icp_scratch_bytes;
   void* icp_pinned;    // ICP: pinned host mirror of the 33 values
@@ -66,6 +69,7 @@ struct IntegrateParams
   const uint8_t* dists;  // half image, row pitch in bytes
   const f32x2* thr;      // per-pixel {A2, B2} band thresholds, dense rows x cols
   const float* coarse;   // coarse minima of A2 (group test), cw x ch cells
+  const float* ckpt;     // nullptr, or camera-space x | y | z of every column at layer z0 (3 planes of X*Y floats)
   int cw, ch;
   int grp_enable;
   float grp_margin, grp_cols_hi, grp_rows_hi, grp_span, grp_inv_bk, grp_bias, grp_zmin;
