@@ -83,7 +83,9 @@ const char* yakhip_last_error(void);
 /* Engine knobs that are not part of the reference's API (results never depend on them).  Keys:
  * "z_chunk" (layers walked by one workgroup, 0 = auto), "nontemporal" (0/1), "vx" (cap on voxels per
  * lane: 0 = widest, 1, 2, 4), "group_test" (0/1: coarse culling test of whole voxel runs),
- * "kernel_timing" (0/1, see yakhip_ctx_kernel_time), "zu" (ignored).
+ * "checkpoint" (0/1: slabs with z0 >= 64 start from column positions computed in closed form instead of
+ * replaying z0 additions per column), "tile" (0 or 3..6: wave footprint in the layer), "mc_z_chunk"
+ * (marching-cubes tile depth, 0 = auto), "kernel_timing" (0/1, see yakhip_ctx_kernel_time), "zu" (ignored).
  * Unknown key or value -> YAKHIP_EINVAL. */
 int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value);
 /* Measurement aid with no counterpart in the reference (its only timers are the never-invoked
