@@ -185,6 +185,29 @@ __device__ __forceinline__ f32x2 band_thresholds(float Dp, float trunc_hi)
   return out;
 }
 
+// A slab that starts at layer z0 of a tall volume needs every column's camera-space position after the z0
+// rounded additions the reference performed below it.  Replaying them in the integrate kernel costs z0 steps
+// per chunk start -- for the last of 8 ranks of a 1024-layer volume more than the rank's own work, and all
+// workgroups do it at the same time, with the memory system idle.  Here they are done once per column and
+// frame, in closed form (ffwd.hpp: bit-identical to the loop), by extra workgroups of the prepass launch,
+// and the integrate kernels start from that.
+constexpr int kCheckpointFrom = 64;  // slabs starting below this layer replay from 0 as before
+
+__device__ __forceinline__ void checkpoint_column(const IntegrateParams& p, float* out, uint32_t col)
+{
+  if (col >= p.plane)
+    return;
+  const int y = (int)(col / (uint32_t)p.X), x = (int)(col - (uint32_t)y * (uint32_t)p.X);
+  // tsdf_volume.cu:69, 71-72, exactly as integrate_kernel starts a column
+  const float vxx = (float)x * p.vsx, vxy = (float)y * p.vsy;
+  const float vx0 = dot3(p.R[0], p.R[1], p.R[2], vxx, vxy, 0.f) + p.t[0];
+  const float vy0 = dot3(p.R[3], p.R[4], p.R[5], vxx, vxy, 0.f) + p.t[1];
+  const float vz0 = dot3(p.R[6], p.R[7], p.R[8], vxx, vxy, 0.f) + p.t[2];
+  out[col] = yak_ffwd_accumulate(vx0, p.R[2] * p.vsz, p.z0);
+  out[p.plane + col] = yak_ffwd_accumulate(vy0, p.R[5] * p.vsz, p.z0);
+  out[2u * p.plane + col] = yak_ffwd_accumulate(vz0, p.R[8] * p.vsz, p.z0);
+}
+
 // One launch per frame, two jobs (both read only the half ray-distance image):
 //   blocks [0, thr_blocks)   per-pixel {A2, B2}                       -> thr[rows][cols]
 //   blocks [thr_blocks, ..)  coarse[by][bx] = min A2 over the pixel window
@@ -193,8 +216,15 @@ __device__ __forceinline__ f32x2 band_thresholds(float Dp, float trunc_hi)
 //                            corner lies in cell (bx, by) is inside that window.
 __global__ __launch_bounds__(256) void prepass_kernel(const uint8_t* dists, uint32_t dists_pitch, int rows, int cols,
                                                       float trunc_hi, f32x2* thr, float* coarse, int cw, int ch,
-                                                      int bk, uint32_t thr_blocks_x, uint32_t thr_blocks)
+                                                      int bk, uint32_t thr_blocks_x, uint32_t thr_blocks,
+                                                      uint32_t ckpt_first_block, const IntegrateParams cp,
+                                                      float* ckpt_out)
 {
+  if (blockIdx.x >= ckpt_first_block)  // workgroups behind the image's: the column checkpoints of a deep slab
+  {
+    checkpoint_column(cp, ckpt_out, (blockIdx.x - ckpt_first_block) * 256u + threadIdx.x);
+    return;
+  }
   if (blockIdx.x < thr_blocks)
   {
     const int x = (int)((blockIdx.x % thr_blocks_x) * 256u + threadIdx.x);
@@ -702,29 +732,7 @@ static int launch_variant(yakhip_ctx* ctx, const IntegrateParams& p, dim3 grid)
   return check(hipGetLastError(), "integrate_kernel launch");
 }
 
-// A slab that starts at layer z0 of a tall volume needs every column's camera-space position after the z0
-// rounded additions the reference performed below it.  Replaying them in the integrate kernel costs z0 steps
-// per chunk start -- for the last of 8 ranks of a 1024-layer volume more than the rank's own work, and all
-// workgroups do it at the same time, with the memory system idle.  Here they are done once per column and
-// frame, in closed form (ffwd.hpp: bit-identical to the loop), and the integrate kernels start from that.
-constexpr int kCheckpointFrom = 64;  // slabs starting below this layer replay from 0 as before
-
-__global__ __launch_bounds__(256) void checkpoint_kernel(const IntegrateParams p, float* out)
-{
-  const uint32_t col = blockIdx.x * 256u + threadIdx.x;
-  if (col >= p.plane)
-    return;
-  const int y = (int)(col / (uint32_t)p.X), x = (int)(col - (uint32_t)y * (uint32_t)p.X);
-  // tsdf_volume.cu:69, 71-72, exactly as integrate_kernel starts a column
-  const float vxx = (float)x * p.vsx, vxy = (float)y * p.vsy;
-  const float vx0 = dot3(p.R[0], p.R[1], p.R[2], vxx, vxy, 0.f) + p.t[0];
-  const float vy0 = dot3(p.R[3], p.R[4], p.R[5], vxx, vxy, 0.f) + p.t[1];
-  const float vz0 = dot3(p.R[6], p.R[7], p.R[8], vxx, vxy, 0.f) + p.t[2];
-  out[col] = yak_ffwd_accumulate(vx0, p.R[2] * p.vsz, p.z0);
-  out[p.plane + col] = yak_ffwd_accumulate(vy0, p.R[5] * p.vsz, p.z0);
-  out[2u * p.plane + col] = yak_ffwd_accumulate(vz0, p.R[8] * p.vsz, p.z0);
-}
-
+// scratch for the column checkpoints of slot `slot` (see checkpoint_column); sets p.ckpt or leaves it null
 static int prepare_checkpoint(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slots)
 {
   p.ckpt = nullptr;
@@ -743,10 +751,7 @@ static int prepare_checkpoint(yakhip_ctx* ctx, IntegrateParams& p, int slot, int
     YAKHIP_TRY(hipMalloc(&ctx->ckpt, slot_bytes * (size_t)slots));
     ctx->ckpt_bytes = slot_bytes * (size_t)slots;
   }
-  float* out = (float*)((char*)ctx->ckpt + slot_bytes * (size_t)slot);
-  hipLaunchKernelGGL(checkpoint_kernel, dim3((p.plane + 255u) / 256u), dim3(256), 0, ctx->stream, p, out);
-  YAKHIP_TRY(hipGetLastError());
-  p.ckpt = out;
+  p.ckpt = (const float*)((char*)ctx->ckpt + slot_bytes * (size_t)slot);
   return 0;
 }
 
@@ -783,12 +788,16 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
   p.thr = (const f32x2*)base;
   p.coarse = (const float*)(base + thr_bytes);
   {
+    const int rc = prepare_checkpoint(ctx, p, slot, slots);
+    if (rc != 0)
+      return rc;
     const uint32_t thr_blocks_x = (uint32_t)((p.cols + 255) / 256);
     const uint32_t thr_blocks = thr_blocks_x * (uint32_t)p.rows;
     const uint32_t cell_blocks = (uint32_t)((p.cw * p.ch + 3) / 4);
-    hipLaunchKernelGGL(prepass_kernel, dim3(thr_blocks + cell_blocks), dim3(256), 0, ctx->stream, p.dists,
+    const uint32_t ckpt_blocks = p.ckpt ? (p.plane + 255u) / 256u : 0u;
+    hipLaunchKernelGGL(prepass_kernel, dim3(thr_blocks + cell_blocks + ckpt_blocks), dim3(256), 0, ctx->stream, p.dists,
                        p.dists_pitch, p.rows, p.cols, p.trunc_hi, (f32x2*)base, (float*)(base + thr_bytes), p.cw, p.ch,
-                       bk, thr_blocks_x, thr_blocks);
+                       bk, thr_blocks_x, thr_blocks, thr_blocks + cell_blocks, p, const_cast<float*>(p.ckpt));
     YAKHIP_TRY(hipGetLastError());
   }
 
@@ -818,7 +827,7 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
     p.grp_enable = ctx->group_test && p.fx > 0.f && p.fy > 0.f && p.cols < 32768 && p.rows < 32768 &&
                    std::isfinite(P) && std::isfinite(f) && coarse_bytes <= coarse_cap_bytes;
   }
-  return prepare_checkpoint(ctx, p, slot, slots);
+  return 0;
 }
 
 // z_chunk and grid for a plane of `blocks_x` workgroups.  Short chunks balance the load: the cost of a
