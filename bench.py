@@ -225,12 +225,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # rehearsal of the multi-rank path on a box with fewer GPUs than ranks (tests/test_bench_ranks_gpu.py):
+    # YAK_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and talks over gloo (RCCL refuses two ranks on one device)
+    share_gpu = os.environ.get("YAK_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- workload ---------------------------------------------------------------------------------
     if emulate:
@@ -321,7 +329,8 @@ def main():
     torch.cuda.synchronize()
     rmw_ceiling = 8.0 * slab_voxels / (ceil0.elapsed_time(ceil1) / 10 * 1e-3) / 1e9
 
-    totals = torch.tensor([elapsed, float(updated), kernel_ms, step_ms], dtype=torch.float64, device="cuda")
+    totals = torch.tensor([elapsed, float(updated), kernel_ms, step_ms], dtype=torch.float64,
+                          device="cpu" if share_gpu else "cuda")
     if dist is not None:
         mx = totals.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)

@@ -1,0 +1,36 @@
+"""bench.py's N > 1 path, rehearsed on one GPU: two ranks launched by torch.distributed.run exactly as the
+driver launches them, both on GPU 0 and over gloo (YAK_BENCH_SHARE_GPU=1; RCCL refuses two ranks on one
+device).  Checks the contract of the one JSON line: whole-job value, max-over-ranks time, weak scaling."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_through_torch_distributed_run():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, YAK_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                                   # rank 0 prints, once
+    d = json.loads(lines[0])
+    assert d["metric"] == "voxel updates/sec" and d["unit"] == "Gvox/s" and d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["steps"] == 20 and d["warmup"] == 3 and d["vs_baseline"] is None
+    assert d["config"]["voxels_updated_per_step"] == 2 * 512 ** 3              # both slabs, every voxel updates
+    assert "1024x512x512" in d["config"]["workload"] and d["config"]["parallelism"] == "z-slab x2"
+    # value = all ranks' voxels over the slowest rank's time
+    assert abs(d["value"] - 2 * 512 ** 3 / (d["ms_per_step"] * 1e-3) / 1e9) < 0.01 * d["value"]
+    assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
