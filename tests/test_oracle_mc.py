@@ -14,7 +14,7 @@ import oracle
 # the vertex list of DIPYRAMID_MESH_ASCII, test/marching_cubes_tests.cpp:24-29 (data, scale 0.01)
 DIPYRAMID_VERTICES = np.float32([[0.01, 0.005, 0.01], [0.005, 0.01, 0.01], [0.01, 0.01, 0.005], [0.015, 0.01, 0.01],
                                  [0.01, 0.01, 0.015], [0.01, 0.015, 0.01]])
-TABLE_CRC = 0x67D04515  # of yak_amd/csrc/mc_case_table.h, printed by tools/gen_mc_case_table.py
+TABLE_CRC = 0x67D04515  # of yak_amd/csrc/mc_case_table.h, printed by tests/golden/gen_mc_case_table.py
 
 
 def clean(tris):
