@@ -84,6 +84,10 @@ public:
 
   Affine3f getCameraPose(int time = -1) const;
 
+  /** The zero crossings of the volume as points in the frame the volume pose maps to (kinfu.hpp:116,
+   *  kinfu.cpp:368-377; at most 10 M points, tsdf_volume.cpp:149-155). */
+  std::vector<Point> downloadCloud() const;
+
 private:
   void allocate_buffers();
 

@@ -318,6 +318,30 @@ int yakhip_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], con
 int yakhip_marching_cubes(yakhip_ctx* ctx, const yakhip_volume* vol, int min_weight, double scale, void* triangles_dev,
                           unsigned long long capacity_triangles, unsigned long long* n_triangles_host);
 
+/* ---- cloud extraction --------------------------------------------------- */
+
+/* Replaces kfusion::device::extractCloud (internal.hpp:163; yak/src/cuda/tsdf_volume.cu:464-665, 764-780):
+ * every voxel with weight != 0 and tsdf != 1 gives one point for each of its +x, +y, +z neighbours that
+ * also has weight != 0, tsdf != 1 and the opposite strict sign -- the linear zero crossing between the two
+ * voxel CENTRES ((i + 0.5) * voxel_size) -- mapped by aff = (R, t), the volume pose
+ * (yak/src/kfusion/tsdf_volume.cpp:147-168).  points_dev: float4 {x, y, z, 0}, 16-byte aligned.
+ * BLOCKING.  *n_points_host receives the number of points the slab holds; the first
+ * min(n, capacity_points) of them are written (the reference stops at its buffer's size the same way,
+ * :639-642); points_dev == NULL only counts.  The point SET equals the reference's; the order is this
+ * library's (deterministic), the reference's comes from a global atomic counter (:616).
+ * A slab [z0, z1) gives the points of the voxels z0 .. z1 - 2: overlap slabs by one layer as for
+ * yakhip_marching_cubes. */
+int yakhip_extract_cloud(yakhip_ctx* ctx, const yakhip_volume* vol, const float R[9], const float t[3], void* points_dev,
+                         unsigned long long capacity_points, unsigned long long* n_points_host);
+
+/* Replaces kfusion::device::extractNormals (internal.hpp:164-165; tsdf_volume.cu:672-763, 782-797): for
+ * every point (in the frame of aff = (R, t)) the central-difference gradient of the trilinear tsdf at
+ * Rinv * (p - t), rotated by R and normalised; quiet NaN where the nearest voxel is within 2 of a face of
+ * the volume.  Whole volume only.  normals_dev: float4 {x, y, z, 0}.  Not blocking. */
+int yakhip_extract_normals(yakhip_ctx* ctx, const yakhip_volume* vol, const void* points_dev, unsigned long long n_points,
+                           const float R[9], const float t[3], const float Rinv[9], float gradient_delta_factor,
+                           void* normals_dev);
+
 #ifdef __cplusplus
 }
 #endif

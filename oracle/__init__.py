@@ -318,5 +318,36 @@ def marching_cubes(volume, dims, min_weight=4, scale=1.0, tables=None):
     return out
 
 
+def extract_cloud(volume, dims, voxel_size, R, t):
+    """Zero crossings between neighbouring voxel centres, mapped by (R, t).  Returns float32 (n, 4)."""
+    dims = np.ascontiguousarray(dims, dtype=np.int32)
+    vol = np.ascontiguousarray(volume, dtype=np.uint32).reshape(-1)
+    assert vol.size == int(dims[0]) * int(dims[1]) * int(dims[2])
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32).reshape(-1)  # noqa: E731
+    L = lib()
+    L.yko_extract_cloud.restype = C.c_uint64
+    L.yko_extract_cloud.argtypes = [_u32p, _i32p, _f32p, _f32p, _f32p, C.c_void_p, C.c_uint64]
+    n = L.yko_extract_cloud(vol, dims, f32(voxel_size), f32(R), f32(t), None, 0)
+    out = np.empty((n, 4), dtype=np.float32)
+    if n:
+        assert L.yko_extract_cloud(vol, dims, f32(voxel_size), f32(R), f32(t), out.ctypes.data, n) == n
+    return out
+
+
+def extract_normals(volume, dims, voxel_size, points, R, t, Rinv, gradient_delta_factor=0.5):
+    """Normals of extract_cloud's points.  Returns float32 (n, 4), NaN near the volume's faces."""
+    dims = np.ascontiguousarray(dims, dtype=np.int32)
+    vol = np.ascontiguousarray(volume, dtype=np.uint32).reshape(-1)
+    pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 4)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32).reshape(-1)  # noqa: E731
+    L = lib()
+    L.yko_extract_normals.restype = None
+    L.yko_extract_normals.argtypes = [_u32p, _i32p, _f32p, C.c_void_p, C.c_uint64, _f32p, _f32p, _f32p, C.c_float, C.c_void_p]
+    out = np.empty_like(pts)
+    L.yko_extract_normals(vol, dims, f32(voxel_size), pts.ctypes.data, len(pts), f32(R), f32(t), f32(Rinv),
+                          float(gradient_delta_factor), out.ctypes.data)
+    return out
+
+
 def max_threads():
     return int(lib().yko_max_threads())

@@ -824,6 +824,99 @@ uint64_t yko_marching_cubes(const uint32_t* volume, const int dims[3], int min_w
   return n;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Cloud extraction: tsdf_volume.cu:464-800.
+ * ------------------------------------------------------------------------------------------ */
+static inline int cloud_voxel(const uint32_t* vol, const int dims[3], int x, int y, int z, float* F)
+{ /* FullScan6::fetch, cu:485-489: unpack_tsdf; returns "W != 0 && F != 1.f" (cu:524, 532, ...) */
+  const uint32_t w = vol[(size_t)x + (size_t)dims[0] * ((size_t)y + (size_t)dims[1] * (size_t)z)];
+  *F = yko_half2float((uint16_t)(w & 0xffffu));
+  return (w >> 16) != 0 && *F != 1.f;
+}
+
+uint64_t yko_extract_cloud(const uint32_t* volume, const int dims[3], const float voxel_size[3], const float R[9],
+                           const float t[3], float* points, uint64_t capacity)
+{
+  uint64_t n = 0;
+  const int X = dims[0], Y = dims[1], Z = dims[2];
+  for (int z = 0; z < Z - 1; ++z) /* cu:514 */
+    for (int y = 0; y < Y; ++y)
+      for (int x = 0; x < X; ++x)
+      {
+        float F;
+        if (!cloud_voxel(volume, dims, x, y, z, &F)) /* cu:522-524 */
+          continue;
+        const float V[3] = { ((float)x + 0.5f) * voxel_size[0], ((float)y + 0.5f) * voxel_size[1],
+                             ((float)z + 0.5f) * voxel_size[2] }; /* cu:508-509, 526 */
+        for (int axis = 0; axis < 3; ++axis) /* cu:528-591: dx, dy, dz */
+        {
+          const int nx = x + (axis == 0), ny = y + (axis == 1), nz = z + (axis == 2);
+          if (nx >= X || ny >= Y) /* (z + 1 < Z by the loop) */
+            continue;
+          float Fn;
+          if (!cloud_voxel(volume, dims, nx, ny, nz, &Fn))
+            continue;
+          if (!((F > 0 && Fn < 0) || (F < 0 && Fn > 0)))
+            continue;
+          float p[3] = { V[0], V[1], V[2] };
+          const float Vn = V[axis] + voxel_size[axis];
+          const float d_inv = 1.f / (fabsf(F) + fabsf(Fn));
+          p[axis] = (V[axis] * fabsf(Fn) + Vn * fabsf(F)) * d_inv;
+          if (n < capacity)
+          { /* aff * p, device.hpp:106-111 */
+            float* o = points + 4 * n;
+            o[0] = dot3(R[0], R[1], R[2], p[0], p[1], p[2]) + t[0];
+            o[1] = dot3(R[3], R[4], R[5], p[0], p[1], p[2]) + t[1];
+            o[2] = dot3(R[6], R[7], R[8], p[0], p[1], p[2]) + t[2];
+            o[3] = 0.f;
+          }
+          ++n;
+        }
+      }
+  return n;
+}
+
+void yko_extract_normals(const uint32_t* volume, const int dims[3], const float voxel_size[3], const float* points,
+                         uint64_t n_points, const float R[9], const float t[3], const float Rinv[9],
+                         float gradient_delta_factor, float* normals)
+{
+  Raycaster rc; /* for interpolate(): cu:167-192 */
+  memset(&rc, 0, sizeof(rc));
+  rc.vol = volume;
+  rc.X = dims[0], rc.Y = dims[1], rc.Z = dims[2];
+  rc.ivx = 1.f / voxel_size[0], rc.ivy = 1.f / voxel_size[1], rc.ivz = 1.f / voxel_size[2]; /* cu:684-689 */
+  const float gdx = voxel_size[0] * gradient_delta_factor, gdy = voxel_size[1] * gradient_delta_factor,
+              gdz = voxel_size[2] * gradient_delta_factor; /* cu:786 */
+  for (uint64_t i = 0; i < n_points; ++i)
+  {
+    const float* q = points + 4 * i;
+    float n[3] = { NAN, NAN, NAN };
+    /* cu:715  point = Rinv * (tr(p) - aff.t) */
+    const float wx = q[0] - t[0], wy = q[1] - t[1], wz = q[2] - t[2];
+    const float px = dot3(Rinv[0], Rinv[1], Rinv[2], wx, wy, wz), py = dot3(Rinv[3], Rinv[4], Rinv[5], wx, wy, wz),
+                pz = dot3(Rinv[6], Rinv[7], Rinv[8], wx, wy, wz);
+    /* cu:694-701  __float2int_rn; the comparisons below reject NaN and anything out of int range first */
+    const float fx = nearbyintf(px * rc.ivx), fy = nearbyintf(py * rc.ivy), fz = nearbyintf(pz * rc.ivz);
+    if (fx > 1.f && fy > 1.f && fz > 1.f && fx < (float)(rc.X - 2) && fy < (float)(rc.Y - 2) && fz < (float)(rc.Z - 2))
+    { /* cu:718-751 */
+      const float Fx1 = interpolate(&rc, (px + gdx) * rc.ivx, py * rc.ivy, pz * rc.ivz);
+      const float Fx2 = interpolate(&rc, (px - gdx) * rc.ivx, py * rc.ivy, pz * rc.ivz);
+      const float Fy1 = interpolate(&rc, px * rc.ivx, (py + gdy) * rc.ivy, pz * rc.ivz);
+      const float Fy2 = interpolate(&rc, px * rc.ivx, (py - gdy) * rc.ivy, pz * rc.ivz);
+      const float Fz1 = interpolate(&rc, px * rc.ivx, py * rc.ivy, (pz + gdz) * rc.ivz);
+      const float Fz2 = interpolate(&rc, px * rc.ivx, py * rc.ivy, (pz - gdz) * rc.ivz);
+      const float gx = (Fx1 - Fx2) / gdx, gy = (Fy1 - Fy2) / gdy, gz = (Fz1 - Fz2) / gdz;
+      /* cu:753  n = normalized(aff.R * n) */
+      n[0] = dot3(R[0], R[1], R[2], gx, gy, gz);
+      n[1] = dot3(R[3], R[4], R[5], gx, gy, gz);
+      n[2] = dot3(R[6], R[7], R[8], gx, gy, gz);
+      normalize3(&n[0], &n[1], &n[2]);
+    }
+    float* o = normals + 4 * i;
+    o[0] = n[0], o[1] = n[1], o[2] = n[2], o[3] = 0.f;
+  }
+}
+
 int yko_max_threads(void)
 {
 #ifdef _OPENMP

@@ -145,6 +145,25 @@ void yko_icp_accumulate(const float R[9], const float t[3], const float intr[4],
 uint64_t yko_marching_cubes(const uint32_t* volume, const int dims[3], int min_weight, double scale,
                             const int* tri_table, const int* edge_connections, float* triangles, uint64_t capacity);
 
+/* ---- cloud extraction: src/cuda/tsdf_volume.cu:464-800 (FullScan6, ExtractNormals) --------------
+ * parity unpinned: the reference holds no vector for it (and its own output order is nondeterministic:
+ * a global atomic counter, :616). */
+
+/* tsdf_volume.cu:468-665 + tsdf_volume.cpp:147-168: every voxel (x, y, z < Z - 1) with weight != 0 and
+ * tsdf != 1 gives one point per axis neighbour (x + 1, y + 1, z + 1, inside the volume) that also has
+ * weight != 0, tsdf != 1 and the opposite strict sign: the linear zero crossing between the two voxel
+ * CENTRES ((i + 0.5) * voxel_size), mapped by aff = (R, t) (the volume pose).  points: float4 {x, y, z, 0},
+ * visiting order z, y, x, then dx, dy, dz.  Writes at most `capacity` points; returns the number found. */
+uint64_t yko_extract_cloud(const uint32_t* volume, const int dims[3], const float voxel_size[3], const float R[9],
+                           const float t[3], float* points, uint64_t capacity);
+
+/* tsdf_volume.cu:672-763 + tsdf_volume.cpp:170-183: for every point, back in the volume frame
+ * (Rinv * (p - t)), the normalised central-difference gradient of the trilinear tsdf, rotated by R;
+ * NaN where the nearest voxel is within 2 of the volume's faces.  normals: float4 {x, y, z, 0}. */
+void yko_extract_normals(const uint32_t* volume, const int dims[3], const float voxel_size[3], const float* points,
+                         uint64_t n_points, const float R[9], const float t[3], const float Rinv[9],
+                         float gradient_delta_factor, float* normals);
+
 int yko_max_threads(void);
 
 #ifdef __cplusplus

@@ -8,6 +8,8 @@
 
 #include "../../yak_amd/csrc/solve6.hpp"
 
+#include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -434,6 +436,80 @@ static void test_marching_cubes_dipyramid()
   EXPECT(yak::marchingCubesCPU(volume, mc).polygons.empty());
 }
 
+// KinFu::downloadCloud / TsdfVolume::fetchCloud / fetchNormals (reference kinfu.cpp:368-377,
+// tsdf_volume.cpp:147-183) against the oracle on the same fused volume: the same point set, and for the
+// library's own point order the same normals, bit for bit.
+static void test_cloud_and_normals_against_oracle()
+{
+  std::printf("KinFu::downloadCloud / TsdfVolume::fetchNormals vs oracle\n");
+  kfusion::KinFuParams p = kfusion::KinFuParams::default_params();
+  p.volume_dims = kfusion::Vec3i(96, 80, 72);
+  p.volume_resolution = 3.f / 96.f;
+  p.volume_pose = rot_y_translate(0.2f, -1.4f, -1.2f, 0.6f);
+  p.use_icp = false;
+  p.use_pose_hints = true;
+  p.update_via_sensor_motion = false;
+  kfusion::KinFu kinfu(p);
+  EXPECT(kinfu.downloadCloud().empty());  // an empty volume has no zero crossing
+  for (int f = 0; f < 3; ++f)
+  {
+    const Affine3f pose = orbit_pose(f * 4);
+    std::vector<std::uint16_t> depth = render_s2(pose, p.intr, p.rows, p.cols);
+    kfusion::cuda::Depth d;
+    d.upload(depth.data(), (size_t)p.cols * 2, p.rows, p.cols);
+    kinfu(Affine3f::Identity(), pose, pose, d);
+  }
+  const kfusion::cuda::TsdfVolume& tv = kinfu.tsdf();
+  std::vector<std::uint32_t> vol((size_t)96 * 80 * 72);
+  tv.data().download(vol.data());
+  const int dims[3] = { 96, 80, 72 };
+  const Vec3f vs = tv.getVoxelSize();
+  const float vsz[3] = { vs[0], vs[1], vs[2] };
+  const Affine3f aff = tv.getPose();
+  const auto R = aff.rotation();
+  const auto Rinv = aff.rotation().inv(cv::DECOMP_SVD);
+  const float t[3] = { aff.translation()[0], aff.translation()[1], aff.translation()[2] };
+
+  std::vector<kfusion::Point> got = kinfu.downloadCloud();
+  const std::uint64_t n = yko_extract_cloud(vol.data(), dims, vsz, R.val, t, nullptr, 0);
+  std::vector<float> want((size_t)n * 4);
+  yko_extract_cloud(vol.data(), dims, vsz, R.val, t, want.data(), n);
+  std::printf("  %zu points (oracle %llu)\n", got.size(), (unsigned long long)n);
+  EXPECT(got.size() == n && n > 1000);
+  typedef std::array<std::uint32_t, 4> Bits;
+  std::vector<Bits> a(got.size()), b((size_t)n);
+  for (size_t i = 0; i < got.size(); ++i)
+    std::memcpy(a[i].data(), got[i].data, 16);
+  for (size_t i = 0; i < (size_t)n; ++i)
+    std::memcpy(b[i].data(), &want[i * 4], 16);
+  std::sort(a.begin(), a.end());
+  std::sort(b.begin(), b.end());
+  EXPECT(a == b);
+
+  // fetchCloud into a caller's small buffer stops at its size (tsdf_volume.cu:639-642)
+  kfusion::cuda::DeviceArray<kfusion::Point> small(100), buffer;
+  EXPECT(tv.fetchCloud(small).size() == 100);
+  kfusion::cuda::DeviceArray<kfusion::Point> cloud = tv.fetchCloud(buffer);
+  EXPECT(buffer.size() == 10u * 1000 * 1000 && cloud.size() == n && cloud.ptr() == buffer.ptr());
+  kfusion::cuda::DeviceArray<kfusion::Normal> normals;
+  tv.fetchNormals(cloud, normals);
+  EXPECT(normals.size() == cloud.size());
+  std::vector<kfusion::Point> pts(cloud.size()), nrm(cloud.size());
+  cloud.download(pts.data());
+  normals.download(nrm.data());
+  std::vector<float> want_n(pts.size() * 4);
+  yko_extract_normals(vol.data(), dims, vsz, pts[0].data, pts.size(), R.val, t, Rinv.val, p.gradient_delta_factor,
+                      want_n.data());
+  size_t diff = 0, nan = 0;
+  for (size_t i = 0; i < pts.size(); ++i)
+  {
+    diff += std::memcmp(nrm[i].data, &want_n[i * 4], 12) != 0 && !(std::isnan(nrm[i].x) && std::isnan(want_n[i * 4]));
+    nan += std::isnan(nrm[i].x);
+  }
+  std::printf("  %zu normals differ, %zu NaN\n", diff, nan);
+  EXPECT(diff == 0 && nan < pts.size() / 2);
+}
+
 static void test_device_arrays()
 {
   std::printf("DeviceArray / DeviceArray2D\n");
@@ -475,6 +551,7 @@ int main(int argc, char** argv)
       test_fusion_server_against_oracle();
       test_kinfu_icp_tracks_orbit();
       test_marching_cubes_dipyramid();
+      test_cloud_and_normals_against_oracle();
     }
   }
   catch (const std::exception& e)

@@ -20,7 +20,7 @@ EXPORTS = [
     "yakhip_raycast_points", "yakhip_raycast_depth", "yakhip_raycast_slab", "yakhip_raycast_resolve", "yakhip_raycast_halo",
     "yakhip_bilateral_filter", "yakhip_truncate_depth", "yakhip_depth_pyramid", "yakhip_compute_points_normals",
     "yakhip_resize_points_normals", "yakhip_icp_accumulate", "yakhip_icp_accumulate_rows", "yakhip_icp_estimate",
-    "yakhip_marching_cubes",
+    "yakhip_marching_cubes", "yakhip_extract_cloud", "yakhip_extract_normals",
 ]
 
 
@@ -116,6 +116,8 @@ def load():
         "yakhip_resize_points_normals": [vp, vp, sz, vp, sz, i, i, vp, sz, vp, sz],
         "yakhip_icp_estimate": [vp, fp, fp, fp, C.c_float, C.c_float, C.POINTER(IcpLevel), i, fp, fp, C.POINTER(i)],
         "yakhip_marching_cubes": [vp, volp, i, C.c_double, vp, C.c_ulonglong, C.POINTER(C.c_ulonglong)],
+        "yakhip_extract_cloud": [vp, volp, fp, fp, vp, C.c_ulonglong, C.POINTER(C.c_ulonglong)],
+        "yakhip_extract_normals": [vp, volp, vp, C.c_ulonglong, fp, fp, fp, C.c_float, vp],
         "yakhip_icp_accumulate": [vp, fp, fp, fp, i, C.c_float, C.c_float, vp, sz, vp, sz, vp, sz, vp, sz, i, i, fp,
                                   C.POINTER(i)],
     }
@@ -324,6 +326,17 @@ class Context:
         _chk(load().yakhip_marching_cubes(self._h, C.byref(vol), int(min_weight), float(scale),
                                           C.c_void_p(triangles_ptr or 0), int(capacity), C.byref(n)))
         return n.value
+
+    def extract_cloud(self, vol, R, t, points_ptr=None, capacity=0):
+        """Blocking.  Returns the number of points the slab holds; writes min(n, capacity) of them."""
+        n = C.c_ulonglong(0)
+        _chk(load().yakhip_extract_cloud(self._h, C.byref(vol), _f32(R, 9), _f32(t, 3), C.c_void_p(points_ptr), int(capacity),
+                                         C.byref(n)))
+        return n.value
+
+    def extract_normals(self, vol, points_ptr, n_points, R, t, Rinv, normals_ptr, gradient_delta_factor=0.5):
+        _chk(load().yakhip_extract_normals(self._h, C.byref(vol), C.c_void_p(points_ptr), int(n_points), _f32(R, 9), _f32(t, 3),
+                                           _f32(Rinv, 9), gradient_delta_factor, C.c_void_p(normals_ptr)))
 
 
 def raycast_halo(vol, step_factor=0.75, gradient_delta_factor=0.5):

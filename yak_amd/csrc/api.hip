@@ -788,6 +788,57 @@ int yakhip_raycast_resolve(yakhip_ctx* ctx, const yakhip_volume* vol, int z_own0
   return launch_raycast_resolve(ctx, p);
 }
 
+// ---- cloud extraction ---------------------------------------------------------------------------
+
+int yakhip_extract_cloud(yakhip_ctx* ctx, const yakhip_volume* vol, const float R[9], const float t[3], void* points_dev,
+                         unsigned long long capacity_points, unsigned long long* n_points_host)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_volume(vol)) != 0)
+    return rc;
+  if (!R || !t || !n_points_host)
+    return fail(YAKHIP_EINVAL, "extract_cloud: null pose or count pointer");
+  if (points_dev && ((uintptr_t)points_dev & 15) != 0)
+    return fail(YAKHIP_EALIGN, "extract_cloud: points buffer not 16-byte aligned");
+  return launch_extract_cloud(ctx, (const uint32_t*)vol->data, vol->dims[0], vol->dims[1], vol->z0, vol->z1 - vol->z0,
+                              vol->voxel_size, R, t, (float*)points_dev, capacity_points, n_points_host);
+}
+
+int yakhip_extract_normals(yakhip_ctx* ctx, const yakhip_volume* vol, const void* points_dev, unsigned long long n_points,
+                           const float R[9], const float t[3], const float Rinv[9], float gradient_delta_factor,
+                           void* normals_dev)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_volume(vol)) != 0)
+    return rc;
+  if (vol->z0 != 0 || vol->z1 != vol->dims[2])
+    return fail(YAKHIP_EINVAL, "extract_normals: needs the whole volume, got the slab [%d, %d) of %d layers", vol->z0,
+                vol->z1, vol->dims[2]);
+  if (!R || !t || !Rinv || !(gradient_delta_factor > 0.f))
+    return fail(YAKHIP_EINVAL, "extract_normals: null pose or non-positive gradient delta factor");
+  if (n_points == 0)
+    return 0;
+  if (!points_dev || !normals_dev)
+    return fail(YAKHIP_EINVAL, "extract_normals: null buffer");
+  if ((((uintptr_t)points_dev | (uintptr_t)normals_dev) & 15) != 0)
+    return fail(YAKHIP_EALIGN, "extract_normals: buffers not 16-byte aligned");
+  RaycastParams p;
+  memset(&p, 0, sizeof(p));
+  p.vol = (const uint32_t*)vol->data;
+  p.X = vol->dims[0], p.Y = vol->dims[1], p.Z = vol->dims[2];
+  p.vsx = vol->voxel_size[0], p.vsy = vol->voxel_size[1], p.vsz = vol->voxel_size[2];
+  p.ivx = 1.f / p.vsx, p.ivy = 1.f / p.vsy, p.ivz = 1.f / p.vsz;  // tsdf_volume.cu:684-689
+  p.gdx = p.vsx * gradient_delta_factor, p.gdy = p.vsy * gradient_delta_factor, p.gdz = p.vsz * gradient_delta_factor;
+  memcpy(p.R, R, sizeof(p.R));
+  memcpy(p.t, t, sizeof(p.t));
+  memcpy(p.Rinv, Rinv, sizeof(p.Rinv));
+  return launch_extract_normals(ctx, p, points_dev, normals_dev, n_points);
+}
+
 // ---- tracking side: depth pre-processing and ICP ----------------------------------------------
 
 int yakhip_bilateral_filter(yakhip_ctx* ctx, const void* src_dev, size_t src_pitch, void* dst_dev, size_t dst_pitch,

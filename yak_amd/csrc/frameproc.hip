@@ -169,6 +169,103 @@ __global__ __launch_bounds__(256) void resize_points_normals_kernel(const uint8_
   ((float4*)(ndst + (size_t)y * ndst_pitch))[x] = n;
 }
 
+// ---- debug display: imgproc.cu:400-561 ----
+
+// __saturatef: NaN -> 0, clamp to [0, 1]
+__device__ __forceinline__ float saturate(float v) { return v > 0.f ? (v < 1.f ? v : 1.f) : 0.f; }
+
+// v^20 by squaring -- the same five products in the oracle, so the two agree bit for bit; the reference's
+// __powf (imgproc.cu:441) is the hardware's exp2(20 * log2 v) approximation, which no CPU or AMD routine
+// reproduces to the bit
+__device__ __forceinline__ float pow20(float v)
+{
+  const float v2 = v * v, v4 = v2 * v2, v5 = v4 * v, v10 = v5 * v5;
+  return v10 * v10;
+}
+
+__device__ __forceinline__ uint32_t grey(float c) { return (uint32_t)(saturate(c) * 255.f) * 0x010101u; }
+
+// :414-418 / :467-471 -- the backdrop where there is no surface: a vertical gradient, stored b, g, r, 0
+__device__ __forceinline__ uint32_t backdrop(int y, int rows)
+{
+  const float w = (float)y / (float)rows;
+  const float b = (4.f / 255.f) * (1 - w) + (236.f / 255.f) * w;
+  const float g = (2.f / 255.f) * (1 - w) + (120.f / 255.f) * w;
+  return (uint32_t)(saturate(b) * 255.f) | (uint32_t)(saturate(g) * 255.f) << 8 | (uint32_t)(saturate(g) * 255.f) << 16;
+}
+
+// :422-443 / :475-496 -- Phong with Ka 0.3, Kd 0.5, Ks 0.2, power 20, white light at light_pose, eye at 0
+__device__ __forceinline__ uint32_t phong(float px, float py, float pz, float4 n, float lx, float ly, float lz)
+{
+  float Lx = lx - px, Ly = ly - py, Lz = lz - pz;
+  float s = 1.0f / __builtin_sqrtf(dot3(Lx, Ly, Lz, Lx, Ly, Lz));
+  Lx *= s, Ly *= s, Lz *= s;
+  float Vx = 0.f - px, Vy = 0.f - py, Vz = 0.f - pz;
+  s = 1.0f / __builtin_sqrtf(dot3(Vx, Vy, Vz, Vx, Vy, Vz));
+  Vx *= s, Vy *= s, Vz *= s;
+  const float nl = dot3(n.x, n.y, n.z, Lx, Ly, Lz);
+  float Rx = 2 * n.x * nl - Lx, Ry = 2 * n.y * nl - Ly, Rz = 2 * n.z * nl - Lz;
+  s = 1.0f / __builtin_sqrtf(dot3(Rx, Ry, Rz, Rx, Ry, Rz));
+  Rx *= s, Ry *= s, Rz *= s;
+  const float rv = dot3(Rx, Ry, Rz, Vx, Vy, Vz);
+  const float Ix = 0.3f + 0.5f * (nl > 0.f ? nl : 0.f) + 0.2f * pow20(rv > 0.f ? rv : 0.f);
+  return grey(Ix);
+}
+
+// DEPTH = false: imgproc.cu:453-504 (points), true: :400-451 (depth in mm through the reprojector)
+template <bool DEPTH>
+__global__ __launch_bounds__(256) void render_image_kernel(const uint8_t* src, uint32_t src_pitch, const uint8_t* normals,
+                                                           uint32_t normals_pitch, int rows, int cols, float finvx,
+                                                           float finvy, float cx, float cy, float lx, float ly, float lz,
+                                                           uint8_t* image, uint32_t image_pitch)
+{
+  const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+  const int y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+  if (x >= cols || y >= rows)
+    return;
+  uint32_t out;
+  if (DEPTH)
+  {
+    const int d = u16_at(src, src_pitch, y, x);
+    if (d == 0)
+      out = backdrop(y, rows);
+    else
+    {
+      const float z = (float)d * 0.001f;
+      float px, py;
+      reproj(finvx, finvy, cx, cy, x, y, z, px, py);
+      out = phong(px, py, z, f4_at(normals, normals_pitch, y, x), lx, ly, lz);
+    }
+  }
+  else
+  {
+    const float4 p = f4_at(src, src_pitch, y, x);
+    out = p.x != p.x ? backdrop(y, rows) : phong(p.x, p.y, p.z, f4_at(normals, normals_pitch, y, x), lx, ly, lz);
+  }
+  ((uint32_t*)(image + (size_t)y * image_pitch))[x] = out;
+}
+
+// float -> unsigned char as the GPU conversion of imgproc.cu:545-547 does it: truncate, NaN -> 0; a unit
+// normal gives 38 .. 216, anything else is clamped to the byte
+__device__ __forceinline__ uint32_t tangent_byte(float n, float k)
+{
+  const float v = (5.f - n * k) * 25.5f;
+  return v > 0.f ? (v < 255.f ? (uint32_t)v : 255u) : 0u;
+}
+
+// imgproc.cu:530-550
+__global__ __launch_bounds__(256) void tangent_colors_kernel(const uint8_t* normals, uint32_t normals_pitch, int rows,
+                                                             int cols, uint8_t* image, uint32_t image_pitch)
+{
+  const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+  const int y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+  if (x >= cols || y >= rows)
+    return;
+  const float4 n = f4_at(normals, normals_pitch, y, x);
+  const uint32_t r = tangent_byte(n.x, 3.5f), g = tangent_byte(n.y, 2.5f), b = tangent_byte(n.z, 3.5f);
+  ((uint32_t*)(image + (size_t)y * image_pitch))[x] = b | g << 8 | r << 16;
+}
+
 inline dim3 image_grid(int rows, int cols) { return dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 3) / 4)); }
 }  // namespace
 
@@ -219,5 +316,31 @@ int launch_resize_points_normals(const yakhip_ctx* ctx, const uint8_t* points, s
                      (uint32_t)points_pitch, normals, (uint32_t)normals_pitch, points_out, (uint32_t)points_out_pitch,
                      normals_out, (uint32_t)normals_out_pitch, rows, cols);
   return check(hipGetLastError(), "resize_points_normals_kernel launch");
+}
+
+int launch_render_image(const yakhip_ctx* ctx, bool from_depth, const uint8_t* src, size_t src_pitch, const uint8_t* normals,
+                        size_t normals_pitch, int rows, int cols, const float reproj_args[4], const float light[3],
+                        uint8_t* image, size_t image_pitch)
+{
+  // internal.hpp:80 Reprojector(fx, fy, cx, cy): finv = 1 / f
+  const float finvx = from_depth ? 1.f / reproj_args[0] : 0.f, finvy = from_depth ? 1.f / reproj_args[1] : 0.f;
+  const float cx = from_depth ? reproj_args[2] : 0.f, cy = from_depth ? reproj_args[3] : 0.f;
+  if (from_depth)
+    hipLaunchKernelGGL(render_image_kernel<true>, image_grid(rows, cols), dim3(256), 0, ctx->stream, src,
+                       (uint32_t)src_pitch, normals, (uint32_t)normals_pitch, rows, cols, finvx, finvy, cx, cy, light[0],
+                       light[1], light[2], image, (uint32_t)image_pitch);
+  else
+    hipLaunchKernelGGL(render_image_kernel<false>, image_grid(rows, cols), dim3(256), 0, ctx->stream, src,
+                       (uint32_t)src_pitch, normals, (uint32_t)normals_pitch, rows, cols, finvx, finvy, cx, cy, light[0],
+                       light[1], light[2], image, (uint32_t)image_pitch);
+  return check(hipGetLastError(), "render_image_kernel launch");
+}
+
+int launch_tangent_colors(const yakhip_ctx* ctx, const uint8_t* normals, size_t normals_pitch, int rows, int cols,
+                          uint8_t* image, size_t image_pitch)
+{
+  hipLaunchKernelGGL(tangent_colors_kernel, image_grid(rows, cols), dim3(256), 0, ctx->stream, normals,
+                     (uint32_t)normals_pitch, rows, cols, image, (uint32_t)image_pitch);
+  return check(hipGetLastError(), "tangent_colors_kernel launch");
 }
 }  // namespace yakhip

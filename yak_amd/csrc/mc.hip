@@ -414,7 +414,184 @@ __global__ __launch_bounds__(1024) void mc_scan_blocks_kernel(unsigned long long
   if (threadIdx.x == 0)
     *total = carry;
 }
+// ---- cloud extraction: kfusion::device::extractCloud (yak/src/cuda/tsdf_volume.cu:464-665, 764-780) ----------
+// Every voxel with weight != 0 and tsdf != 1 gives a point for each of its +x, +y, +z neighbours that also has
+// weight != 0, tsdf != 1 and the opposite strict sign: the zero crossing between the two voxel centres,
+// mapped by the volume pose.  The reference appends through a global atomic counter (:616), so its order
+// changes from run to run; here the same count -> scan -> emit schedule as marching cubes fixes every
+// point's slot (tile, z, row, x, then dx, dy, dz).  Same wave tile too: 63 owner voxels along x (lane i + 1
+// supplies the +x neighbour) by 4 owner rows (a fifth row supplies +y), walking z with the next layer in
+// registers; a tile layer with no negative voxel cannot hold a sign change and costs five compares.
+struct CloudParams
+{
+  const uint32_t* vol;  // first held layer
+  int X, Y;
+  int z0;               // global index of the first held layer
+  int pair_layers;      // layers z that have z + 1 inside the slab
+  int nx, ny;           // wave tiles along x and y
+  int z_chunk, nzc, z_sub, nzs;
+  float vsx, vsy, vsz;
+  float R[9], t[3];
+  unsigned long long capacity;
+};
+
+// "W != 0 && F != 1.f" (tsdf_volume.cu:524, 535, ...) and the value
+__device__ __forceinline__ bool cloud_voxel(uint32_t word, float& F)
+{
+  F = half_bits_to_float(word & 0xffffu);
+  return (word >> 16) != 0 && F != 1.f;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void cloud_kernel(const CloudParams p, uint32_t* counts, const uint32_t* local_offsets,
+                                                    const unsigned long long* block_bases, float4* points)
+{
+  const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  // count pass: every XCD gets a contiguous run of workgroups (shared lines and rows meet in one L2); the
+  // emit pass keeps round-robin so that the few tiles with surface spread over the XCDs (see mc_kernel)
+  const unsigned n_wg = gridDim.x, per_xcd = n_wg / 8u;
+  const unsigned wg =
+      !EMIT && blockIdx.x < per_xcd * 8u ? (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u : blockIdx.x;
+  const unsigned gy = (unsigned)(p.ny + 3) / 4u;
+  const int xt = (int)(wg % (unsigned)p.nx), yt = (int)((wg / (unsigned)p.nx) % gy) * 4 + wave,
+            zc = (int)(wg / ((unsigned)p.nx * gy));
+  if (yt >= p.ny)
+    return;
+  const int walk = EMIT ? p.z_sub : p.z_chunk;
+  const size_t tile_stride = (size_t)p.ny * p.nx;
+  size_t tile = ((size_t)zc * (size_t)(walk / p.z_sub) * p.ny + yt) * p.nx + xt;
+  unsigned long long out = 0;
+  if (EMIT)
+  {
+    if (counts[tile] == 0)
+      return;
+    out = block_bases[tile / kScanBlock] + local_offsets[tile];
+  }
+
+  const int x = xt * kRun + lane, y0 = yt * kRows;
+  const bool in_x = x < p.X;
+  const bool owner = lane < kRun && in_x;       // this lane's voxels are counted here
+  const bool has_x1 = owner && x + 1 < p.X;     // ... and have a +x neighbour (in lane + 1)
+  const size_t plane = (size_t)p.X * p.Y;
+  const int zl0 = zc * walk, zl1 = min(zl0 + walk, p.pair_layers);
+
+  uint32_t row_off[kRows + 1];
+#pragma unroll
+  for (int r = 0; r <= kRows; ++r)
+    row_off[r] = (uint32_t)min(y0 + r, p.Y - 1) * (uint32_t)p.X + (uint32_t)(in_x ? x : 0);
+  auto any_negative = [&](const uint32_t(&w)[kRows + 1]) {
+    uint64_t any = 0;
+#pragma unroll
+    for (int r = 0; r <= kRows; ++r)
+      any |= __builtin_amdgcn_ballot_w64(half_bits_to_float(w[r] & 0xffffu) < 0.f);
+    return any != 0;
+  };
+
+  const uint32_t* layer = p.vol + (size_t)zl0 * plane;
+  uint32_t w_lo[kRows + 1], w_ahead[kRows + 1];
+#pragma unroll
+  for (int r = 0; r <= kRows; ++r)
+    w_lo[r] = layer[row_off[r]];
+  layer += plane;
+#pragma unroll
+  for (int r = 0; r <= kRows; ++r)
+    w_ahead[r] = layer[row_off[r]];
+  bool lo_negative = any_negative(w_lo);
+  unsigned n_mine = 0;
+
+  for (int zl = zl0; zl < zl1; ++zl)
+  {
+    uint32_t w_hi[kRows + 1];
+    if (zl + 2 <= p.pair_layers)
+      layer += plane;
+#pragma unroll
+    for (int r = 0; r <= kRows; ++r)
+    {
+      w_hi[r] = w_ahead[r];
+      w_ahead[r] = layer[row_off[r]];
+    }
+    const bool hi_negative = any_negative(w_hi);
+    const bool near_surface = lo_negative || hi_negative;  // wave-uniform: a sign change needs a negative voxel
+    lo_negative = hi_negative;
+
+#pragma unroll
+    for (int r = 0; r < kRows; ++r)
+    {
+      if (!near_surface)
+        break;
+      // tsdf_volume.cu:519-591 for the voxel (x, y0 + r, z0 + zl)
+      float F, Fx, Fy, Fz;
+      const bool ok = cloud_voxel(w_lo[r], F) && owner && y0 + r < p.Y;
+      const bool okx = cloud_voxel(__shfl_down(w_lo[r], 1, 64), Fx) && has_x1;
+      const bool oky = cloud_voxel(w_lo[r + 1], Fy) && y0 + r + 1 < p.Y;
+      const bool okz = cloud_voxel(w_hi[r], Fz);
+      const bool cx = ok && okx && ((F > 0.f && Fx < 0.f) || (F < 0.f && Fx > 0.f));
+      const bool cy = ok && oky && ((F > 0.f && Fy < 0.f) || (F < 0.f && Fy > 0.f));
+      const bool cz = ok && okz && ((F > 0.f && Fz < 0.f) || (F < 0.f && Fz > 0.f));
+      const unsigned cnt = (unsigned)cx + (unsigned)cy + (unsigned)cz;
+      if (!EMIT)
+        n_mine += cnt;
+      else if (__builtin_amdgcn_ballot_w64(cnt != 0) != 0)  // wave-uniform
+      {
+        unsigned incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+        {
+          const unsigned up = __shfl_up(incl, off, 64);
+          if (lane >= off)
+            incl += up;
+        }
+        const unsigned total = __shfl(incl, 63, 64);
+        unsigned long long slot = out + (incl - cnt);
+        // :508-509, 526  voxel centre
+        const float Vx = ((float)x + 0.5f) * p.vsx, Vy = ((float)(y0 + r) + 0.5f) * p.vsy,
+                    Vz = ((float)(p.z0 + zl) + 0.5f) * p.vsz;
+        auto put = [&](float px, float py, float pz) {  // aff * p, device.hpp:106-111
+          if (slot < p.capacity)
+            points[slot] = make_float4(dot3(p.R[0], p.R[1], p.R[2], px, py, pz) + p.t[0],
+                                       dot3(p.R[3], p.R[4], p.R[5], px, py, pz) + p.t[1],
+                                       dot3(p.R[6], p.R[7], p.R[8], px, py, pz) + p.t[2], 0.f);
+          ++slot;
+        };
+        // :539-545  p = (V * |Fn| + Vn * |F|) * (1 / (|F| + |Fn|)) along the axis of the neighbour
+        const float aF = __builtin_fabsf(F);
+        if (cx)
+        {
+          const float aN = __builtin_fabsf(Fx), d_inv = 1.f / (aF + aN);
+          put((Vx * aN + (Vx + p.vsx) * aF) * d_inv, Vy, Vz);
+        }
+        if (cy)
+        {
+          const float aN = __builtin_fabsf(Fy), d_inv = 1.f / (aF + aN);
+          put(Vx, (Vy * aN + (Vy + p.vsy) * aF) * d_inv, Vz);
+        }
+        if (cz)
+        {
+          const float aN = __builtin_fabsf(Fz), d_inv = 1.f / (aF + aN);
+          put(Vx, Vy, (Vz * aN + (Vz + p.vsz) * aF) * d_inv);
+        }
+        out += total;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r <= kRows; ++r)
+      w_lo[r] = w_hi[r];
+    if (!EMIT && ((zl + 1 - zl0) % p.z_sub == 0 || zl + 1 == zl1))  // a tile is complete
+    {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1)
+        n_mine += __shfl_xor(n_mine, off, 64);
+      if (lane == 0)
+        counts[tile] = n_mine;
+      tile += tile_stride;
+      n_mine = 0;
+    }
+  }
+}
 }  // namespace
+
+static int tile_scratch(yakhip_ctx* ctx, size_t n_tiles, uint32_t** counts, uint32_t** local_offsets,
+                        unsigned long long** block_bases, unsigned long long** total, size_t* n_blocks_out);
 
 int launch_marching_cubes(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int z0, int layers, int min_weight,
                           double scale, float* triangles, unsigned long long capacity, unsigned long long* n_out)
@@ -445,29 +622,14 @@ int launch_marching_cubes(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, in
     return fail(YAKHIP_ERANGE, "marching_cubes: more than a million voxel rows");
   const size_t n_tiles = (size_t)p.nx * p.ny * p.nzs;
 
-  // context-owned scratch: counts (u32) | local offsets (u32) | block bases (u64) | total (u64), and a
-  // pinned host word
-  const size_t n_blocks = (n_tiles + kScanBlock - 1) / kScanBlock;
-  const size_t counts_bytes = (n_tiles * sizeof(uint32_t) + 15) & ~(size_t)15;
-  const size_t need = 2 * counts_bytes + (n_blocks + 1) * sizeof(unsigned long long);
-  if (ctx->mc_scratch_bytes < need)
+  uint32_t *counts, *local_offsets;
+  unsigned long long *block_bases, *total;
+  size_t n_blocks;
   {
-    if (ctx->mc_scratch)
-    {
-      YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
-      YAKHIP_TRY(hipFree(ctx->mc_scratch));
-    }
-    ctx->mc_scratch = nullptr;
-    ctx->mc_scratch_bytes = 0;
-    YAKHIP_TRY(hipMalloc(&ctx->mc_scratch, need));
-    ctx->mc_scratch_bytes = need;
+    const int rc = tile_scratch(ctx, n_tiles, &counts, &local_offsets, &block_bases, &total, &n_blocks);
+    if (rc != 0)
+      return rc;
   }
-  if (!ctx->mc_pinned)
-    YAKHIP_TRY(hipHostMalloc(&ctx->mc_pinned, sizeof(unsigned long long), hipHostMallocDefault));
-  uint32_t* counts = (uint32_t*)ctx->mc_scratch;
-  uint32_t* local_offsets = (uint32_t*)((uint8_t*)ctx->mc_scratch + counts_bytes);
-  unsigned long long* block_bases = (unsigned long long*)((uint8_t*)ctx->mc_scratch + 2 * counts_bytes);
-  unsigned long long* total = block_bases + n_blocks;
 
   const size_t wgs_layer = (size_t)p.nx * gy;
   if (wgs_layer * (size_t)p.nzs > 0x7fffffffull)
@@ -497,6 +659,98 @@ int launch_marching_cubes(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, in
     return rc;
   hipLaunchKernelGGL((mc_kernel<true>), grid_emit, dim3(256), 0, ctx->stream, p, counts, local_offsets, block_bases,
                      triangles);
+  if ((rc = timing_end(ctx, ev)) != 0)
+    return rc;
+  YAKHIP_TRY(hipGetLastError());
+  return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+// scratch of the count -> scan -> emit passes: counts (u32) | local offsets (u32) | block bases (u64) | total
+static int tile_scratch(yakhip_ctx* ctx, size_t n_tiles, uint32_t** counts, uint32_t** local_offsets,
+                        unsigned long long** block_bases, unsigned long long** total, size_t* n_blocks_out)
+{
+  const size_t n_blocks = (n_tiles + kScanBlock - 1) / kScanBlock;
+  const size_t counts_bytes = (n_tiles * sizeof(uint32_t) + 15) & ~(size_t)15;
+  const size_t need = 2 * counts_bytes + (n_blocks + 1) * sizeof(unsigned long long);
+  if (ctx->mc_scratch_bytes < need)
+  {
+    if (ctx->mc_scratch)
+    {
+      YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
+      YAKHIP_TRY(hipFree(ctx->mc_scratch));
+    }
+    ctx->mc_scratch = nullptr;
+    ctx->mc_scratch_bytes = 0;
+    YAKHIP_TRY(hipMalloc(&ctx->mc_scratch, need));
+    ctx->mc_scratch_bytes = need;
+  }
+  if (!ctx->mc_pinned)
+    YAKHIP_TRY(hipHostMalloc(&ctx->mc_pinned, sizeof(unsigned long long), hipHostMallocDefault));
+  *counts = (uint32_t*)ctx->mc_scratch;
+  *local_offsets = (uint32_t*)((uint8_t*)ctx->mc_scratch + counts_bytes);
+  *block_bases = (unsigned long long*)((uint8_t*)ctx->mc_scratch + 2 * counts_bytes);
+  *total = *block_bases + n_blocks;
+  *n_blocks_out = n_blocks;
+  return 0;
+}
+
+int launch_extract_cloud(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int z0, int layers, const float vs[3],
+                         const float R[9], const float t[3], float* points, unsigned long long capacity,
+                         unsigned long long* n_out)
+{
+  *n_out = 0;
+  if (layers < 2)
+    return 0;  // tsdf_volume.cu:514: the z loop stops one layer short
+  if ((unsigned long long)X * (unsigned long long)Y > (1ull << 30))
+    return fail(YAKHIP_ERANGE, "extract_cloud: a layer of more than 2^30 voxels");
+  CloudParams p;
+  p.vol = vol;
+  p.X = X, p.Y = Y, p.z0 = z0;
+  p.pair_layers = layers - 1;
+  p.nx = (X + kRun - 1) / kRun;
+  p.ny = (Y + kRows - 1) / kRows;
+  p.z_sub = 8;
+  p.z_chunk = 16;
+  p.nzs = (p.pair_layers + p.z_sub - 1) / p.z_sub;
+  p.nzc = (p.pair_layers + p.z_chunk - 1) / p.z_chunk;
+  p.vsx = vs[0], p.vsy = vs[1], p.vsz = vs[2];
+  for (int i = 0; i < 9; ++i)
+    p.R[i] = R[i];
+  for (int i = 0; i < 3; ++i)
+    p.t[i] = t[i];
+  p.capacity = points ? capacity : 0;
+  const unsigned gy = (unsigned)((p.ny + 3) / 4);
+  const size_t n_tiles = (size_t)p.nx * p.ny * p.nzs, wgs_layer = (size_t)p.nx * gy;
+  if (wgs_layer * (size_t)p.nzs > 0x7fffffffull)
+    return fail(YAKHIP_ERANGE, "extract_cloud: more than 2^31 workgroups");
+  uint32_t *counts, *local_offsets;
+  unsigned long long *block_bases, *total;
+  size_t n_blocks;
+  int rc = tile_scratch(ctx, n_tiles, &counts, &local_offsets, &block_bases, &total, &n_blocks);
+  if (rc != 0)
+    return rc;
+
+  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  if ((rc = timing_begin(ctx, &ev)) != 0)
+    return rc;
+  hipLaunchKernelGGL((cloud_kernel<false>), dim3((unsigned)(wgs_layer * p.nzc)), dim3(256), 0, ctx->stream, p, counts,
+                     local_offsets, block_bases, (float4*)nullptr);
+  YAKHIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(mc_scan_local_kernel, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, counts, local_offsets,
+                     n_tiles, block_bases);
+  hipLaunchKernelGGL(mc_scan_blocks_kernel, dim3(1), dim3(1024), 0, ctx->stream, block_bases, n_blocks, total);
+  if ((rc = timing_end(ctx, ev)) != 0)
+    return rc;
+  YAKHIP_TRY(hipGetLastError());
+  YAKHIP_TRY(hipMemcpyAsync(ctx->mc_pinned, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
+  const unsigned long long n = *(const unsigned long long*)ctx->mc_pinned;
+  *n_out = n;
+  if (!points || n == 0 || capacity == 0)
+    return 0;
+  if ((rc = timing_begin(ctx, &ev)) != 0)
+    return rc;
+  hipLaunchKernelGGL((cloud_kernel<true>), dim3((unsigned)(wgs_layer * p.nzs)), dim3(256), 0, ctx->stream, p, counts,
+                     local_offsets, block_bases, (float4*)points);
   if ((rc = timing_end(ctx, ev)) != 0)
     return rc;
   YAKHIP_TRY(hipGetLastError());

@@ -338,7 +338,63 @@ __global__ __launch_bounds__(256) void raycast_resolve_kernel(const RaycastParam
   }
   krow[x] = key - 1;
 }
+
+// kfusion::device::extractNormals (tsdf_volume.cu:672-763, 782-797): normals of extracted cloud points.
+// points are in the frame the cloud was extracted into (aff = p.R, p.t); the gradient is taken in the
+// volume frame and rotated back.  No counterpart of raycast's NaN test: a NaN gradient stays NaN.
+template <bool IDX32>
+__global__ __launch_bounds__(256) void extract_normals_kernel(const RaycastParams p, const float4* pts, float4* out,
+                                                              unsigned long long n)
+{
+  const unsigned long long idx = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+  if (idx >= n)
+    return;
+  const float qnan = __builtin_nanf("");
+  float nx = qnan, ny = qnan, nz = qnan;
+  const float4 q = pts[idx];
+  // :715  point = Rinv * (tr(p) - aff.t)
+  const float wx = q.x - p.t[0], wy = q.y - p.t[1], wz = q.z - p.t[2];
+  const float px = dot3(p.Rinv[0], p.Rinv[1], p.Rinv[2], wx, wy, wz), py = dot3(p.Rinv[3], p.Rinv[4], p.Rinv[5], wx, wy, wz),
+              pz = dot3(p.Rinv[6], p.Rinv[7], p.Rinv[8], wx, wy, wz);
+  // :694-701, 718  nearest voxel (round half even) at least 2 away from every face; compared as floats so
+  // that NaN and huge coordinates fail the test instead of overflowing a conversion
+  const float gx = __builtin_rintf(px * p.ivx), gy = __builtin_rintf(py * p.ivy), gz = __builtin_rintf(pz * p.ivz);
+  if (gx > 1.f && gy > 1.f && gz > 1.f && gx < (float)(p.X - 2) && gy < (float)(p.Y - 2) && gz < (float)(p.Z - 2))
+  {
+    bool held = true;
+    const float Fx1 = interpolate<IDX32, false>(p, (px + p.gdx) * p.ivx, py * p.ivy, pz * p.ivz, held);
+    const float Fx2 = interpolate<IDX32, false>(p, (px - p.gdx) * p.ivx, py * p.ivy, pz * p.ivz, held);
+    const float Fy1 = interpolate<IDX32, false>(p, px * p.ivx, (py + p.gdy) * p.ivy, pz * p.ivz, held);
+    const float Fy2 = interpolate<IDX32, false>(p, px * p.ivx, (py - p.gdy) * p.ivy, pz * p.ivz, held);
+    const float Fz1 = interpolate<IDX32, false>(p, px * p.ivx, py * p.ivy, (pz + p.gdz) * p.ivz, held);
+    const float Fz2 = interpolate<IDX32, false>(p, px * p.ivx, py * p.ivy, (pz - p.gdz) * p.ivz, held);
+    const float dx = (Fx1 - Fx2) / p.gdx, dy = (Fy1 - Fy2) / p.gdy, dz = (Fz1 - Fz2) / p.gdz;
+    // :753  n = normalized(aff.R * n)
+    nx = dot3(p.R[0], p.R[1], p.R[2], dx, dy, dz);
+    ny = dot3(p.R[3], p.R[4], p.R[5], dx, dy, dz);
+    nz = dot3(p.R[6], p.R[7], p.R[8], dx, dy, dz);
+    normalize3(nx, ny, nz);
+  }
+  out[idx] = make_float4(nx, ny, nz, 0.f);
+}
 }  // namespace
+
+int launch_extract_normals(yakhip_ctx* ctx, const RaycastParams& p, const void* points, void* normals, unsigned long long n)
+{
+  if (n == 0)
+    return 0;
+  const unsigned long long blocks = (n + 255ull) / 256ull;
+  if (blocks > 0x7fffffffull)
+    return fail(YAKHIP_ERANGE, "extract_normals: too many points");
+  const bool idx32 = (unsigned long long)p.X * (unsigned long long)p.Y * (unsigned long long)p.Z <= (1ull << 30);
+  if (idx32)
+    hipLaunchKernelGGL((extract_normals_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p,
+                       (const float4*)points, (float4*)normals, n);
+  else
+    hipLaunchKernelGGL((extract_normals_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, p,
+                       (const float4*)points, (float4*)normals, n);
+  return check(hipGetLastError(), "extract_normals_kernel launch");
+}
 
 int launch_raycast_resolve(yakhip_ctx* ctx, const RaycastParams& p)
 {

@@ -117,7 +117,8 @@ int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p);
 // n_frames >= 1 frames applied in order to the same slab; thr / coarse / grp_* / z_chunk are filled here
 int launch_integrate_batch(yakhip_ctx* ctx, const IntegrateParams* frames, int n_frames);
 int launch_raycast(yakhip_ctx* ctx, const RaycastParams& p);
-int launch_raycast_resolve(yakhip_ctx* ctx, const RaycastParams& p);  // slab mode, after the composite
+int launch_raycast_resolve(yakhip_ctx* ctx, const RaycastParams& p);
+int launch_extract_normals(yakhip_ctx* ctx, const RaycastParams& p, const void* points, void* normals, unsigned long long n);  // slab mode, after the composite
 int launch_clear(const yakhip_ctx* ctx, uint32_t* data, size_t n_voxels);
 int launch_selftest_division(yakhip_ctx* ctx, unsigned long long counts[4]);
 int launch_compute_dists(const yakhip_ctx* ctx, const uint8_t* depth, size_t depth_pitch, uint8_t* dists,
@@ -147,6 +148,9 @@ int launch_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], c
 // layers are meshed.  Only counts when triangles == nullptr or the count exceeds `capacity`.
 int launch_marching_cubes(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int z0, int layers, int min_weight,
                           double scale, float* triangles, unsigned long long capacity, unsigned long long* n_out);
+int launch_extract_cloud(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int z0, int layers, const float vs[3],
+                         const float R[9], const float t[3], float* points, unsigned long long capacity,
+                         unsigned long long* n_out);
 
 // icp.hip: the device-resident schedule.  status_out: 0 = done, 2 = some system needs the host path.
 int launch_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], float dist_thres,

@@ -112,6 +112,17 @@ Affine3f KinFu::getCameraPose(int time) const  // kinfu.cpp:155-160
   return poses_[time];
 }
 
+// kinfu.cpp:368-377
+std::vector<Point> KinFu::downloadCloud() const
+{
+  cuda::DeviceArray<Point> cloud_buffer;
+  cuda::DeviceArray<Point> extracted = volume_->fetchCloud(cloud_buffer);
+  std::vector<Point> result(extracted.size());
+  if (!result.empty())
+    extracted.download(result.data());
+  return result;
+}
+
 // kinfu.cpp:162-309
 bool KinFu::operator()(const Affine3f& inputCameraMotion, const Affine3f& currentCameraPose,
                        const Affine3f& previousCameraPose, const cuda::Depth& depth, const cuda::Image& /*image*/)

@@ -236,13 +236,36 @@ void TsdfVolume::raycast(const Affine3f& camera_pose, const Intr& intr, Cloud& p
                                   points.ptr(), points.step(), normals.ptr(), normals.step(), points.rows(),
                                   points.cols()));
 }
-DeviceArray<Point> TsdfVolume::fetchCloud(DeviceArray<Point>&) const
+// :147-168.  The volume pose is the affine the points are mapped by; the returned array is a view of the
+// first min(n, capacity) elements of cloud_buffer (DeviceArray(T*, size) does not own).
+DeviceArray<Point> TsdfVolume::fetchCloud(DeviceArray<Point>& cloud_buffer) const
 {
-  throw std::logic_error("TsdfVolume::fetchCloud: out of scope (unused by FusionServer, SURVEY section 2 #4)");
+  enum
+  {
+    DEFAULT_CLOUD_BUFFER_SIZE = 10 * 1000 * 1000
+  };
+  if (cloud_buffer.empty())
+    cloud_buffer.create(DEFAULT_CLOUD_BUFFER_SIZE);
+
+  const Mat3f R = pose_.rotation();
+  const Vec3f t = pose_.translation();
+  yakhip_volume v = make_view(const_cast<void*>(data_.ptr<void>()), dims_, getVoxelSize(), trunc_dist_, max_weight_);
+  unsigned long long n = 0;
+  YAK_CHECK(yakhip_extract_cloud(context(), &v, R.val, t.val, cloud_buffer.ptr(), cloud_buffer.size(), &n));
+  const size_t size = n < cloud_buffer.size() ? (size_t)n : cloud_buffer.size();
+  return DeviceArray<Point>(cloud_buffer.ptr(), size);
 }
-void TsdfVolume::fetchNormals(const DeviceArray<Point>&, DeviceArray<Normal>&) const
+// :170-183
+void TsdfVolume::fetchNormals(const DeviceArray<Point>& cloud, DeviceArray<Normal>& normals) const
 {
-  throw std::logic_error("TsdfVolume::fetchNormals: out of scope (unused by FusionServer, SURVEY section 2 #4)");
+  normals.create(cloud.size());
+  if (cloud.empty())
+    return;
+  const Mat3f R = pose_.rotation(), Rinv = pose_.rotation().inv(cv::DECOMP_SVD);
+  const Vec3f t = pose_.translation();
+  yakhip_volume v = make_view(const_cast<void*>(data_.ptr<void>()), dims_, getVoxelSize(), trunc_dist_, max_weight_);
+  YAK_CHECK(yakhip_extract_normals(context(), &v, cloud.ptr(), cloud.size(), R.val, t.val, Rinv.val,
+                                   gradient_delta_factor_, normals.ptr()));
 }
 
 // ---- imgproc wrappers ----
