@@ -263,7 +263,7 @@ int yakhip_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], c
  * wherever the correspondences fall), left on the device and NOT waited for: sums_dev receives 33 floats,
  * the 27 sums followed by the 6 counts (exact as floats below 2^24).  No counterpart in the reference;
  * it is the piece SURVEY.md 8e's image-space split needs: every GPU takes a band of rows, the 33 values
- * are added over the GPUs (an all-reduce, yak_amd/sharding.py:allreduce_icp_sums), every GPU solves the
+ * are added over the GPUs (an all-reduce, yak_amd/shard.py:allreduce_icp_sums), every GPU solves the
  * same 6 x 6 system.  The order of the additions differs from the one-GPU sum, so A and b agree to
  * rounding (1e-4 relative), not bit for bit.  row_begin == row_end gives zeros. */
 int yakhip_icp_accumulate_rows(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], int level,
