@@ -19,6 +19,14 @@ KF_EXPORTS void depthBuildPyramid(const Depth& depth, Depth& pyramid, float sigm
 KF_EXPORTS void computePointNormals(const Intr& intr, const Depth& depth, Cloud& points, Normals& normals);
 /** 2 x 2 box average of point / normal maps (reference imgproc.cpp:65-80, imgproc.cu:348-394). */
 KF_EXPORTS void resizePointsNormals(const Cloud& points, const Normals& normals, Cloud& points_out, Normals& normals_out);
+/** Debug views, 4 bytes per pixel {b, g, r, 0}; both block like the reference's (imgproc.cpp:82-126,
+ *  imgproc.cu:400-561).  renderImage: Phong shading of camera-frame maps lit from light_pose; the Depth
+ *  overload re-projects with (fx, fy, cx, fy) exactly as imgproc.cpp:92 builds its Reprojector. */
+KF_EXPORTS void renderTangentColors(const Normals& normals, Image& image);
+KF_EXPORTS void renderImage(const Depth& depth, const Normals& normals, const Intr& intr, const Vec3f& light_pose,
+                            Image& image);
+KF_EXPORTS void renderImage(const Cloud& points, const Normals& normals, const Intr& intr, const Vec3f& light_pose,
+                            Image& image);
 /** Blocks until everything queued so far is done (reference imgproc.cpp:21: cudaDeviceSynchronize). */
 KF_EXPORTS void waitAllDefaultStream();
 }  // namespace cuda

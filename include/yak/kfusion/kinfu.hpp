@@ -82,6 +82,12 @@ public:
                   const Affine3f& previousCameraPose, const cuda::Depth& depth,
                   const cuda::Image& image = cuda::Image());
 
+  /** The model as the tracker last saw it (the ray cast of the latest pose): flags 1 = Phong view, 2 = normal
+   *  colours, 3 = both side by side (image is then 2 * cols wide); kinfu.hpp:113, kinfu.cpp:311-335. */
+  void renderImage(cuda::Image& image, int flags = 0);
+  /** The same views of the volume ray-cast from `pose` (kinfu.hpp:114, kinfu.cpp:337-366). */
+  void renderImage(cuda::Image& image, const Affine3f& pose, int flags = 0);
+
   Affine3f getCameraPose(int time = -1) const;
 
   /** The zero crossings of the volume as points in the frame the volume pose maps to (kinfu.hpp:116,

@@ -1,7 +1,9 @@
 // yak/yak_server.h -- yak::FusionServer: feeds depth frames with externally known poses into KinFu
 // and hands back the fused volume (reference yak/include/yak/yak_server.h:24-60,
-// yak/src/yak_server.cpp:4-110).  Headless: the reference opens an OpenCV window in the constructor
-// and renders after every frame (yak_server.cpp:10-12,36); display() is a no-op here.
+// yak/src/yak_server.cpp:4-110).  Headless: the reference opens an OpenCV window in the constructor and
+// shows a rendered view after every frame (yak_server.cpp:10-12,36,90-98).  Here display() renders the
+// same view on the GPU and keeps it in host memory (view()); fuse() does so after every frame only when
+// the environment variable YAK_HIP_DISPLAY is set to a non-zero value.
 #ifndef YAK_OFFLINE_FUSION_SERVER_H_
 #define YAK_OFFLINE_FUSION_SERVER_H_
 
@@ -30,16 +32,27 @@ public:
   bool reset();
   bool resetWithNewParams(const kfusion::KinFuParams& params);
   yak::TSDFContainer downloadTSDF();
+  /** Renders the tracker's current model view (Phong | normal colours, rows x 2 cols) and downloads it
+   *  (yak_server.cpp:100-104); the reference then shows it in a window. */
   void display();
+  /** The same, ray-cast from `pose` (yak_server.cpp:106-110). */
   void display(const Eigen::Affine3f& pose);
+  /** The last view display() produced: rows x cols pixels of 4 bytes {b, g, r, 0}, tightly packed
+   *  (what the reference hands to cv::imshow, yak_server.cpp:92-96).  Empty before the first display(). */
+  const std::vector<unsigned char>& view(int& rows, int& cols) const;
 
 private:
   bool step(const Eigen::Affine3f& current_pose, const Eigen::Affine3f& last_pose, const cv::Mat& depth);
 
   kfusion::KinFu::Ptr kinfu_;
+  void downloadView();
+
   kfusion::cuda::Depth depthDevice_;
   Eigen::Affine3f volume_to_world_;
   Eigen::Affine3f last_camera_pose_;
+  kfusion::cuda::Image viewDevice_;
+  std::vector<unsigned char> viewHost_;
+  bool display_every_frame_;
 };
 }  // namespace yak
 #endif

@@ -342,6 +342,30 @@ int yakhip_extract_normals(yakhip_ctx* ctx, const yakhip_volume* vol, const void
                            const float R[9], const float t[3], const float Rinv[9], float gradient_delta_factor,
                            void* normals_dev);
 
+/* ---- debug display ------------------------------------------------------
+ * Images: 4 bytes per pixel {b, g, r, 0} (kfusion::RGB, yak/include/yak/kfusion/types.hpp:39-49), row
+ * pitch a multiple of 4.  Not blocking. */
+
+/* Replaces kfusion::device::renderImage, Points overload (internal.hpp:167-171; yak/src/cuda/imgproc.cu:453-504,
+ * 517-524): Phong shading (ambient 0.3, diffuse 0.5, specular 0.2 with power 20, white light at light_pose,
+ * eye at the origin) of the camera-frame vertex / normal maps; pixels whose point is NaN get the vertical
+ * backdrop gradient.  The specular power is v^20 by five multiplications; the reference's __powf is
+ * the CUDA hardware's exp2(20 log2 v) approximation, so grey levels may differ by one (parity unpinned). */
+int yakhip_render_image_points(yakhip_ctx* ctx, const void* points_dev, size_t points_pitch, const void* normals_dev,
+                               size_t normals_pitch, int rows, int cols, const float light_pose[3], void* image_dev,
+                               size_t image_pitch);
+/* Replaces kfusion::device::renderImage, Depth overload (internal.hpp:162-166; imgproc.cu:400-451, 508-515):
+ * the same with the vertex re-projected from depth (uint16 mm) by intr = {fx, fy, cx, cy} -- the
+ * Reprojector's arguments as given (the reference's host wrapper passes fy for cy, imgproc.cpp:92). */
+int yakhip_render_image_depth(yakhip_ctx* ctx, const void* depth_dev, size_t depth_pitch, const void* normals_dev,
+                              size_t normals_pitch, int rows, int cols, const float intr[4], const float light_pose[3],
+                              void* image_dev, size_t image_pitch);
+/* Replaces kfusion::device::renderTangentColors (internal.hpp:172; imgproc.cu:530-561):
+ * r, g, b = (uchar)((5 - n.x * 3.5) * 25.5), (5 - n.y * 2.5) * 25.5, (5 - n.z * 3.5) * 25.5; the float ->
+ * uchar conversion truncates and saturates, NaN -> 0, as the GPU conversion does. */
+int yakhip_render_tangent_colors(yakhip_ctx* ctx, const void* normals_dev, size_t normals_pitch, int rows, int cols,
+                                 void* image_dev, size_t image_pitch);
+
 #ifdef __cplusplus
 }
 #endif

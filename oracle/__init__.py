@@ -349,5 +349,42 @@ def extract_normals(volume, dims, voxel_size, points, R, t, Rinv, gradient_delta
     return out
 
 
+def render_image(src, normals, light_pose, intr=None):
+    """Phong view of camera-frame maps.  src: points (rows, cols, 4) float32, or depth (rows, cols) uint16
+    with intr = the Reprojector's {fx, fy, cx, cy}.  Returns (rows, cols, 4) uint8 {b, g, r, 0}."""
+    n = _f4img(normals)
+    rows, cols = n.shape[:2]
+    img = np.empty((rows, cols, 4), dtype=np.uint8)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32).reshape(-1)  # noqa: E731
+    L = lib()
+    vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+    if intr is None:
+        p = _f4img(src)
+        assert p.shape == n.shape
+        L.yko_render_image_points.restype = None
+        L.yko_render_image_points.argtypes = [vp, sz, vp, sz, i, i, _f32p, vp, sz]
+        L.yko_render_image_points(p.ctypes.data, cols * 16, n.ctypes.data, cols * 16, rows, cols, f32(light_pose),
+                                  img.ctypes.data, cols * 4)
+    else:
+        d = _u16img(src)
+        assert d.shape == (rows, cols)
+        L.yko_render_image_depth.restype = None
+        L.yko_render_image_depth.argtypes = [vp, sz, vp, sz, i, i, _f32p, _f32p, vp, sz]
+        L.yko_render_image_depth(d.ctypes.data, cols * 2, n.ctypes.data, cols * 16, rows, cols, f32(intr),
+                                 f32(light_pose), img.ctypes.data, cols * 4)
+    return img
+
+
+def render_tangent_colors(normals):
+    n = _f4img(normals)
+    rows, cols = n.shape[:2]
+    img = np.empty((rows, cols, 4), dtype=np.uint8)
+    L = lib()
+    L.yko_render_tangent_colors.restype = None
+    L.yko_render_tangent_colors.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    L.yko_render_tangent_colors(n.ctypes.data, cols * 16, rows, cols, img.ctypes.data, cols * 4)
+    return img
+
+
 def max_threads():
     return int(lib().yko_max_threads())

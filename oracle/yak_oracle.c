@@ -652,6 +652,105 @@ void yko_resize_points_normals(const float* points, size_t points_pitch, const f
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Debug display: imgproc.cu:400-561.  Parity unpinned (the reference holds no image for it); the
+ * specular term's __powf(v, 20) (:441, the CUDA hardware's exp2(20 * log2 v) approximation, which no
+ * CPU routine reproduces to the bit) is restated as v^20 by five multiplications, so a grey level may
+ * differ from the reference's by one.
+ * ------------------------------------------------------------------------------------------ */
+static inline float saturatef(float v) { return v > 0.f ? (v < 1.f ? v : 1.f) : 0.f; } /* __saturatef: NaN -> 0 */
+
+static inline float pow20(float v)
+{
+  const float v2 = v * v, v4 = v2 * v2, v5 = v4 * v, v10 = v5 * v5;
+  return v10 * v10;
+}
+
+/* :414-418 / :467-471, stored b, g, r, 0 (:445-450) */
+static inline void backdrop(int y, int rows, uint8_t out[4])
+{
+  const float w = (float)y / (float)rows;
+  const float b = (4.f / 255.f) * (1 - w) + (236.f / 255.f) * w;
+  const float g = (2.f / 255.f) * (1 - w) + (120.f / 255.f) * w;
+  out[0] = (uint8_t)(saturatef(b) * 255.f);
+  out[1] = out[2] = (uint8_t)(saturatef(g) * 255.f);
+  out[3] = 0;
+}
+
+/* :422-443 / :475-496 */
+static inline void phong(const float P[3], const float* N, const float light[3], uint8_t out[4])
+{
+  float Lx = light[0] - P[0], Ly = light[1] - P[1], Lz = light[2] - P[2];
+  normalize3(&Lx, &Ly, &Lz);
+  float Vx = 0.f - P[0], Vy = 0.f - P[1], Vz = 0.f - P[2];
+  normalize3(&Vx, &Vy, &Vz);
+  const float nl = dot3(N[0], N[1], N[2], Lx, Ly, Lz);
+  float Rx = 2 * N[0] * nl - Lx, Ry = 2 * N[1] * nl - Ly, Rz = 2 * N[2] * nl - Lz;
+  normalize3(&Rx, &Ry, &Rz);
+  const float rv = dot3(Rx, Ry, Rz, Vx, Vy, Vz);
+  const float Ix = 0.3f + 0.5f * (nl > 0.f ? nl : 0.f) + 0.2f * pow20(rv > 0.f ? rv : 0.f);
+  out[0] = out[1] = out[2] = (uint8_t)(saturatef(Ix) * 255.f);
+  out[3] = 0;
+}
+
+void yko_render_image_points(const float* points, size_t points_pitch, const float* normals, size_t normals_pitch,
+                             int rows, int cols, const float light_pose[3], uint8_t* image, size_t image_pitch)
+{
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x)
+    {
+      const float* p = F4_AT(points, points_pitch, y, x);
+      uint8_t* out = image + (size_t)y * image_pitch + 4 * (size_t)x;
+      if (isnan(p[0]))
+        backdrop(y, rows, out);
+      else
+        phong(p, F4_AT(normals, normals_pitch, y, x), light_pose, out);
+    }
+}
+
+void yko_render_image_depth(const uint16_t* depth, size_t depth_pitch, const float* normals, size_t normals_pitch,
+                            int rows, int cols, const float intr[4], const float light_pose[3], uint8_t* image,
+                            size_t image_pitch)
+{
+  const float finvx = 1.f / intr[0], finvy = 1.f / intr[1], cx = intr[2], cy = intr[3]; /* precomp.cpp:73-76 */
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x)
+    {
+      const int d = U16_AT(depth, depth_pitch, y, x);
+      uint8_t* out = image + (size_t)y * image_pitch + 4 * (size_t)x;
+      if (d == 0)
+        backdrop(y, rows, out);
+      else
+      {
+        float P[3];
+        reproj(finvx, finvy, cx, cy, x, y, (float)d * 0.001f, P); /* :422 */
+        phong(P, F4_AT(normals, normals_pitch, y, x), light_pose, out);
+      }
+    }
+}
+
+/* :545-547: float -> unsigned char truncates; saturating, NaN -> 0 (a unit normal gives 38 .. 216) */
+static inline uint8_t tangent_byte(float n, float k)
+{
+  const float v = (5.f - n * k) * 25.5f;
+  return v > 0.f ? (v < 255.f ? (uint8_t)v : 255) : 0;
+}
+
+void yko_render_tangent_colors(const float* normals, size_t normals_pitch, int rows, int cols, uint8_t* image,
+                               size_t image_pitch)
+{
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x)
+    {
+      const float* n = F4_AT(normals, normals_pitch, y, x);
+      uint8_t* out = image + (size_t)y * image_pitch + 4 * (size_t)x;
+      out[0] = tangent_byte(n[2], 3.5f); /* :549 make_uchar4(b, g, r, 0) */
+      out[1] = tangent_byte(n[1], 2.5f);
+      out[2] = tangent_byte(n[0], 3.5f);
+      out[3] = 0;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * Projective ICP, one linearisation: proj_icp.cu.
  * ------------------------------------------------------------------------------------------ */
 void yko_icp_accumulate(const float R[9], const float t[3], const float intr[4], int level, float dist_thres,

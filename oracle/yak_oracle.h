@@ -164,6 +164,17 @@ void yko_extract_normals(const uint32_t* volume, const int dims[3], const float 
                          uint64_t n_points, const float R[9], const float t[3], const float Rinv[9],
                          float gradient_delta_factor, float* normals);
 
+/* Debug display, imgproc.cu:400-561 (parity unpinned; the specular power is v^20 by multiplication where the
+ * reference has the approximate __powf).  image: 4 bytes per pixel {b, g, r, 0}. */
+void yko_render_image_points(const float* points, size_t points_pitch_bytes, const float* normals,
+                             size_t normals_pitch_bytes, int rows, int cols, const float light_pose[3], uint8_t* image,
+                             size_t image_pitch_bytes);
+void yko_render_image_depth(const uint16_t* depth, size_t depth_pitch_bytes, const float* normals,
+                            size_t normals_pitch_bytes, int rows, int cols, const float intr[4],
+                            const float light_pose[3], uint8_t* image, size_t image_pitch_bytes);
+void yko_render_tangent_colors(const float* normals, size_t normals_pitch_bytes, int rows, int cols, uint8_t* image,
+                               size_t image_pitch_bytes);
+
 int yko_max_threads(void);
 
 #ifdef __cplusplus

@@ -1,6 +1,7 @@
 // Host-layer tests, in the style the reference tests its own host code (gtest-like cases, no gtest
 // in this image): `test_host --cpu` needs no GPU; `test_host --gpu` drives yak::FusionServer on a
 // real device and checks the downloaded volume word for word against the CPU oracle.
+#include <yak/kfusion/cuda/imgproc.hpp>
 #include <yak/mc/marching_cubes.h>
 #include <yak/yak_server.h>
 
@@ -510,6 +511,101 @@ static void test_cloud_and_normals_against_oracle()
   EXPECT(diff == 0 && nan < pts.size() / 2);
 }
 
+// KinFu::renderImage (both overloads, flags 0 / 2 / 3) and FusionServer::display (reference kinfu.cpp:311-366,
+// yak_server.cpp:90-110) against the oracle's restatement of imgproc.cu:400-561 applied to the same
+// ray-cast maps: every pixel the same four bytes.
+static void test_render_views_against_oracle()
+{
+  std::printf("KinFu::renderImage / FusionServer::display vs oracle\n");
+  kfusion::KinFuParams p = kfusion::KinFuParams::default_params();
+  p.volume_dims = kfusion::Vec3i::all(128);
+  p.volume_resolution = 3.f / 128.f;
+  p.volume_pose = orbit_pose(0);
+  p.use_icp = false;
+  p.use_pose_hints = true;
+  p.update_via_sensor_motion = false;
+  p.light_pose = Vec3f(0.5f, -0.3f, -1.f);
+  kfusion::KinFu kinfu(p);
+  Affine3f pose;
+  for (int f = 0; f < 3; ++f)
+  {
+    pose = orbit_pose(f * 3);
+    std::vector<std::uint16_t> depth = render_s2(pose, p.intr, p.rows, p.cols);
+    kfusion::cuda::Depth d;
+    d.upload(depth.data(), (size_t)p.cols * 2, p.rows, p.cols);
+    kinfu(Affine3f::Identity(), pose, pose, d);
+  }
+  const int rows = p.rows, cols = p.cols;
+  kfusion::cuda::Cloud points;
+  kfusion::cuda::Normals normals;
+  kinfu.tsdf().raycast(pose, p.intr, points, normals);
+  std::vector<float> hp((size_t)rows * cols * 4), hn(hp.size());
+  points.download(hp.data(), (size_t)cols * 16);
+  normals.download(hn.data(), (size_t)cols * 16);
+  std::vector<std::uint8_t> want_phong((size_t)rows * cols * 4), want_tangent(want_phong.size());
+  yko_render_image_points(hp.data(), (size_t)cols * 16, hn.data(), (size_t)cols * 16, rows, cols, p.light_pose.val,
+                          want_phong.data(), (size_t)cols * 4);
+  yko_render_tangent_colors(hn.data(), (size_t)cols * 16, rows, cols, want_tangent.data(), (size_t)cols * 4);
+  size_t lit = 0;
+  for (size_t i = 0; i < (size_t)rows * cols; ++i)
+    lit += !std::isnan(hp[i * 4]);
+  EXPECT(lit > (size_t)rows * cols / 4);
+
+  auto download = [](const kfusion::cuda::Image& img) {
+    std::vector<std::uint8_t> h((size_t)img.rows() * img.cols() * 4);
+    img.download(h.data(), (size_t)img.cols() * 4);
+    return h;
+  };
+  auto half = [&](const std::vector<std::uint8_t>& wide, int which) {  // left / right half of a rows x 2 cols image
+    std::vector<std::uint8_t> out((size_t)rows * cols * 4);
+    for (int y = 0; y < rows; ++y)
+      std::memcpy(&out[(size_t)y * cols * 4], &wide[((size_t)y * 2 + which) * cols * 4], (size_t)cols * 4);
+    return out;
+  };
+  for (int from_pose = 0; from_pose < 2; ++from_pose)  // the tracker's own maps are the ray cast of the last pose
+  {
+    kfusion::cuda::Image image;
+    auto render = [&](int flag) { from_pose ? kinfu.renderImage(image, pose, flag) : kinfu.renderImage(image, flag); };
+    render(0);
+    EXPECT(image.rows() == rows && image.cols() == cols && download(image) == want_phong);
+    render(2);
+    EXPECT(image.rows() == rows && image.cols() == cols && download(image) == want_tangent);
+    render(3);
+    EXPECT(image.rows() == rows && image.cols() == 2 * cols);
+    const std::vector<std::uint8_t> wide = download(image);
+    EXPECT(half(wide, 0) == want_phong && half(wide, 1) == want_tangent);
+  }
+
+  // the Depth overload re-projects with (fx, fy, cx, fy) as imgproc.cpp:92 does
+  kfusion::cuda::Depth depth_map;
+  kfusion::cuda::Normals normals_d;
+  kinfu.tsdf().raycast(pose, p.intr, depth_map, normals_d);
+  std::vector<std::uint16_t> hd((size_t)rows * cols);
+  depth_map.download(hd.data(), (size_t)cols * 2);
+  normals_d.download(hn.data(), (size_t)cols * 16);
+  const float quirk[4] = { p.intr.fx, p.intr.fy, p.intr.cx, p.intr.fy };
+  yko_render_image_depth(hd.data(), (size_t)cols * 2, hn.data(), (size_t)cols * 16, rows, cols, quirk, p.light_pose.val,
+                         want_phong.data(), (size_t)cols * 4);
+  kfusion::cuda::Image image;
+  kfusion::cuda::renderImage(depth_map, normals_d, p.intr, p.light_pose, image);
+  EXPECT(download(image) == want_phong);
+
+  // FusionServer: headless display() keeps the view the reference would show
+  yak::FusionServer server(p, Eigen::Affine3f::Identity());
+  int vr = -1, vc = -1;
+  EXPECT(server.view(vr, vc).empty() && vr == 0 && vc == 0);
+  std::vector<std::uint16_t> depth = render_s2(orbit_pose(0), p.intr, rows, cols);
+  server.fuse(cv::Mat(rows, cols, depth.data(), (size_t)cols * 2), Eigen::Affine3f(orbit_pose(0)));
+  EXPECT(server.view(vr, vc).empty());  // YAK_HIP_DISPLAY is not set: fuse() does not render
+  server.display(Eigen::Affine3f(orbit_pose(2)));
+  const std::vector<std::uint8_t>& view = server.view(vr, vc);
+  EXPECT(vr == rows && vc == 2 * cols && view.size() == (size_t)rows * cols * 8);
+  size_t grey = 0;
+  for (size_t i = 0; i < view.size(); i += 4)
+    grey += view[i] == view[i + 1] && view[i + 1] == view[i + 2] && view[i] > 70;
+  EXPECT(grey > (size_t)rows * cols / 4);  // Phong pixels are grey, at least the ambient 0.3 * 255
+}
+
 static void test_device_arrays()
 {
   std::printf("DeviceArray / DeviceArray2D\n");
@@ -552,6 +648,7 @@ int main(int argc, char** argv)
       test_kinfu_icp_tracks_orbit();
       test_marching_cubes_dipyramid();
       test_cloud_and_normals_against_oracle();
+      test_render_views_against_oracle();
     }
   }
   catch (const std::exception& e)

@@ -21,6 +21,7 @@ EXPORTS = [
     "yakhip_bilateral_filter", "yakhip_truncate_depth", "yakhip_depth_pyramid", "yakhip_compute_points_normals",
     "yakhip_resize_points_normals", "yakhip_icp_accumulate", "yakhip_icp_accumulate_rows", "yakhip_icp_estimate",
     "yakhip_marching_cubes", "yakhip_extract_cloud", "yakhip_extract_normals",
+    "yakhip_render_image_points", "yakhip_render_image_depth", "yakhip_render_tangent_colors",
 ]
 
 
@@ -118,6 +119,9 @@ def load():
         "yakhip_marching_cubes": [vp, volp, i, C.c_double, vp, C.c_ulonglong, C.POINTER(C.c_ulonglong)],
         "yakhip_extract_cloud": [vp, volp, fp, fp, vp, C.c_ulonglong, C.POINTER(C.c_ulonglong)],
         "yakhip_extract_normals": [vp, volp, vp, C.c_ulonglong, fp, fp, fp, C.c_float, vp],
+        "yakhip_render_image_points": [vp, vp, sz, vp, sz, i, i, fp, vp, sz],
+        "yakhip_render_image_depth": [vp, vp, sz, vp, sz, i, i, fp, fp, vp, sz],
+        "yakhip_render_tangent_colors": [vp, vp, sz, i, i, vp, sz],
         "yakhip_icp_accumulate": [vp, fp, fp, fp, i, C.c_float, C.c_float, vp, sz, vp, sz, vp, sz, vp, sz, i, i, fp,
                                   C.POINTER(i)],
     }
@@ -337,6 +341,23 @@ class Context:
     def extract_normals(self, vol, points_ptr, n_points, R, t, Rinv, normals_ptr, gradient_delta_factor=0.5):
         _chk(load().yakhip_extract_normals(self._h, C.byref(vol), C.c_void_p(points_ptr), int(n_points), _f32(R, 9), _f32(t, 3),
                                            _f32(Rinv, 9), gradient_delta_factor, C.c_void_p(normals_ptr)))
+
+    # ---- debug display: images are 4 bytes per pixel {b, g, r, 0} ----
+    def render_image_points(self, points_ptr, points_pitch, normals_ptr, normals_pitch, rows, cols, light_pose, image_ptr,
+                            image_pitch):
+        _chk(load().yakhip_render_image_points(self._h, C.c_void_p(points_ptr), points_pitch, C.c_void_p(normals_ptr),
+                                               normals_pitch, rows, cols, _f32(light_pose, 3), C.c_void_p(image_ptr),
+                                               image_pitch))
+
+    def render_image_depth(self, depth_ptr, depth_pitch, normals_ptr, normals_pitch, rows, cols, intr, light_pose,
+                           image_ptr, image_pitch):
+        _chk(load().yakhip_render_image_depth(self._h, C.c_void_p(depth_ptr), depth_pitch, C.c_void_p(normals_ptr),
+                                              normals_pitch, rows, cols, _f32(intr, 4), _f32(light_pose, 3),
+                                              C.c_void_p(image_ptr), image_pitch))
+
+    def render_tangent_colors(self, normals_ptr, normals_pitch, rows, cols, image_ptr, image_pitch):
+        _chk(load().yakhip_render_tangent_colors(self._h, C.c_void_p(normals_ptr), normals_pitch, rows, cols,
+                                                 C.c_void_p(image_ptr), image_pitch))
 
 
 def raycast_halo(vol, step_factor=0.75, gradient_delta_factor=0.5):

@@ -927,6 +927,60 @@ int yakhip_resize_points_normals(yakhip_ctx* ctx, const void* points_dev, size_t
                                       (uint8_t*)normals_out_dev, normals_out_pitch);
 }
 
+// ---- debug display -----------------------------------------------------------------------------
+
+static int render_image(yakhip_ctx* ctx, bool from_depth, const void* src_dev, size_t src_pitch, const void* normals_dev,
+                        size_t normals_pitch, int rows, int cols, const float intr[4], const float light_pose[3],
+                        void* image_dev, size_t image_pitch)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!light_pose || (from_depth && !intr))
+    return fail(YAKHIP_EINVAL, "render_image: null light position or intrinsics");
+  if (from_depth && (intr[0] == 0.f || intr[1] == 0.f))
+    return fail(YAKHIP_EINVAL, "render_image: zero focal length");
+  if ((rc = check_image(from_depth ? "render_image(depth)" : "render_image(points)", src_dev, src_pitch, rows, cols,
+                        from_depth ? 2 : 16)) != 0)
+    return rc;
+  if ((rc = check_image("render_image(normals)", normals_dev, normals_pitch, rows, cols, 16)) != 0)
+    return rc;
+  if ((rc = check_image("render_image(image)", image_dev, image_pitch, rows, cols, 4)) != 0)
+    return rc;
+  return launch_render_image(ctx, from_depth, (const uint8_t*)src_dev, src_pitch, (const uint8_t*)normals_dev,
+                             normals_pitch, rows, cols, intr, light_pose, (uint8_t*)image_dev, image_pitch);
+}
+
+int yakhip_render_image_points(yakhip_ctx* ctx, const void* points_dev, size_t points_pitch, const void* normals_dev,
+                               size_t normals_pitch, int rows, int cols, const float light_pose[3], void* image_dev,
+                               size_t image_pitch)
+{
+  return render_image(ctx, false, points_dev, points_pitch, normals_dev, normals_pitch, rows, cols, nullptr, light_pose,
+                      image_dev, image_pitch);
+}
+
+int yakhip_render_image_depth(yakhip_ctx* ctx, const void* depth_dev, size_t depth_pitch, const void* normals_dev,
+                              size_t normals_pitch, int rows, int cols, const float intr[4], const float light_pose[3],
+                              void* image_dev, size_t image_pitch)
+{
+  return render_image(ctx, true, depth_dev, depth_pitch, normals_dev, normals_pitch, rows, cols, intr, light_pose,
+                      image_dev, image_pitch);
+}
+
+int yakhip_render_tangent_colors(yakhip_ctx* ctx, const void* normals_dev, size_t normals_pitch, int rows, int cols,
+                                 void* image_dev, size_t image_pitch)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_image("render_tangent_colors(normals)", normals_dev, normals_pitch, rows, cols, 16)) != 0)
+    return rc;
+  if ((rc = check_image("render_tangent_colors(image)", image_dev, image_pitch, rows, cols, 4)) != 0)
+    return rc;
+  return launch_tangent_colors(ctx, (const uint8_t*)normals_dev, normals_pitch, rows, cols, (uint8_t*)image_dev,
+                               image_pitch);
+}
+
 int yakhip_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], int level,
                           float dist_thres, float angle_thres, const void* vcurr_dev, size_t vcurr_pitch,
                           const void* ncurr_dev, size_t ncurr_pitch, const void* vprev_dev, size_t vprev_pitch,

@@ -136,6 +136,12 @@ int launch_resize_points_normals(const yakhip_ctx* ctx, const uint8_t* points, s
                                  const uint8_t* normals, size_t normals_pitch, int src_rows, int src_cols,
                                  uint8_t* points_out, size_t points_out_pitch, uint8_t* normals_out,
                                  size_t normals_out_pitch);
+// debug display (imgproc.cu:400-561).  reproj_args = {fx, fy, cx, cy} of the Reprojector (depth variant only)
+int launch_render_image(const yakhip_ctx* ctx, bool from_depth, const uint8_t* src, size_t src_pitch, const uint8_t* normals,
+                        size_t normals_pitch, int rows, int cols, const float reproj_args[4], const float light[3],
+                        uint8_t* image, size_t image_pitch);
+int launch_tangent_colors(const yakhip_ctx* ctx, const uint8_t* normals, size_t normals_pitch, int rows, int cols,
+                          uint8_t* image, size_t image_pitch);
 // icp.hip (blocking: returns after the 27 sums and 6 counters are on the host)
 int launch_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], int level,
                           float dist_thres, float angle_thres, const uint8_t* vcurr, size_t vcurr_pitch,

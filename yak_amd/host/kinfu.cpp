@@ -112,6 +112,46 @@ Affine3f KinFu::getCameraPose(int time) const  // kinfu.cpp:155-160
   return poses_[time];
 }
 
+namespace
+{
+// kinfu.cpp:322-333 / :353-364
+void render_views(const cuda::Cloud& points, const cuda::Normals& normals, const KinFuParams& p, cuda::Image& image, int flag)
+{
+  if (flag < 1 || flag > 3)
+    cuda::renderImage(points, normals, p.intr, p.light_pose, image);
+  else if (flag == 2)
+    cuda::renderTangentColors(normals, image);
+  else
+  {
+    // two views of the caller's image side by side; create() on a view of the right size keeps its memory
+    cuda::DeviceArray2D<RGB> i1(p.rows, p.cols, image.ptr(), image.step());
+    cuda::DeviceArray2D<RGB> i2(p.rows, p.cols, image.ptr() + p.cols, image.step());
+    cuda::renderImage(points, normals, p.intr, p.light_pose, i1);
+    cuda::renderTangentColors(normals, i2);
+  }
+}
+}  // namespace
+
+// kinfu.cpp:311-335
+void KinFu::renderImage(cuda::Image& image, int flag)
+{
+  const KinFuParams& p = params_;
+  image.create(p.rows, flag != 3 ? p.cols : p.cols * 2);
+  render_views(prev_.points_pyr[0], prev_.normals_pyr[0], p, image, flag);
+}
+
+// kinfu.cpp:337-366
+void KinFu::renderImage(cuda::Image& image, const Affine3f& pose, int flag)
+{
+  const KinFuParams& p = params_;
+  image.create(p.rows, flag != 3 ? p.cols : p.cols * 2);
+  depths_.create(p.rows, p.cols);
+  normals_.create(p.rows, p.cols);
+  points_.create(p.rows, p.cols);
+  volume_->raycast(pose, p.intr, points_, normals_);
+  render_views(points_, normals_, p, image, flag);
+}
+
 // kinfu.cpp:368-377
 std::vector<Point> KinFu::downloadCloud() const
 {

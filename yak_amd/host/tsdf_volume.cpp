@@ -309,5 +309,28 @@ void resizePointsNormals(const Cloud& points, const Normals& normals, Cloud& poi
                                          normals_out.ptr(), normals_out.step()));
 }
 void waitAllDefaultStream() { YAK_CHECK(yakhip_ctx_synchronize(context())); }  // imgproc.cpp:21
+
+void renderImage(const Depth& depth, const Normals& normals, const Intr& intr, const Vec3f& light_pose, Image& image)
+{  // imgproc.cpp:82-98
+  image.create(depth.rows(), depth.cols());
+  const float in[4] = { intr.fx, intr.fy, intr.cx, intr.fy };  // :92 passes fy where cy belongs; kept
+  YAK_CHECK(yakhip_render_image_depth(context(), depth.ptr(), depth.step(), normals.ptr(), normals.step(), depth.rows(),
+                                      depth.cols(), in, light_pose.val, image.ptr(), image.step()));
+  waitAllDefaultStream();
+}
+void renderImage(const Cloud& points, const Normals& normals, const Intr& /*intr*/, const Vec3f& light_pose, Image& image)
+{  // imgproc.cpp:100-116 (the points variant never uses its Reprojector, imgproc.cu:453-504)
+  image.create(points.rows(), points.cols());
+  YAK_CHECK(yakhip_render_image_points(context(), points.ptr(), points.step(), normals.ptr(), normals.step(),
+                                       points.rows(), points.cols(), light_pose.val, image.ptr(), image.step()));
+  waitAllDefaultStream();
+}
+void renderTangentColors(const Normals& normals, Image& image)  // imgproc.cpp:118-126
+{
+  image.create(normals.rows(), normals.cols());
+  YAK_CHECK(yakhip_render_tangent_colors(context(), normals.ptr(), normals.step(), normals.rows(), normals.cols(),
+                                         image.ptr(), image.step()));
+  waitAllDefaultStream();
+}
 }  // namespace cuda
 }  // namespace kfusion

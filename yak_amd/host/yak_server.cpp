@@ -2,6 +2,8 @@
 // yak/src/kfusion/tsdf_container.cpp).
 #include <yak/yak_server.h>
 
+#include <cstdlib>
+
 namespace yak
 {
 TSDFContainer::TSDFContainer(int x, int y, int z)
@@ -35,7 +37,10 @@ FusionServer::FusionServer(const kfusion::KinFuParams& params, const Eigen::Affi
   : kinfu_(new kfusion::KinFu(params))
   , volume_to_world_(world_to_volume.inverse())
   , last_camera_pose_(Eigen::Affine3f::Identity())
+  , display_every_frame_(false)
 {
+  const char* env = std::getenv("YAK_HIP_DISPLAY");
+  display_every_frame_ = env && std::atoi(env) != 0;
 }
 
 // yak_server.cpp:15-39
@@ -48,7 +53,8 @@ bool FusionServer::fuse(const cv::Mat& depth_data, const Eigen::Affine3f& world_
   const bool result =
       kinfu_->operator()(to_kf(motion), to_kf(current_camera_in_volume), to_kf(last_camera_pose_), depthDevice_);
   last_camera_pose_ = current_camera_in_volume;
-  display();
+  if (display_every_frame_)  // yak_server.cpp:36 does this unconditionally (render + download per frame)
+    display();
   return result;
 }
 
@@ -82,6 +88,27 @@ bool FusionServer::step(const Eigen::Affine3f& current_pose, const Eigen::Affine
   return kinfu_->operator()(to_kf(s), to_kf(current_pose), to_kf(last_pose), depthDevice_);
 }
 
-void FusionServer::display() {}
-void FusionServer::display(const Eigen::Affine3f&) {}
+// yak_server.cpp:90-98 without the window
+void FusionServer::downloadView()
+{
+  viewHost_.resize((std::size_t)viewDevice_.rows() * viewDevice_.cols() * 4);
+  if (!viewHost_.empty())
+    viewDevice_.download(viewHost_.data(), (std::size_t)viewDevice_.cols() * 4);
+}
+void FusionServer::display()  // yak_server.cpp:100-104
+{
+  kinfu_->renderImage(viewDevice_, 3);
+  downloadView();
+}
+void FusionServer::display(const Eigen::Affine3f& pose)  // yak_server.cpp:106-110
+{
+  kinfu_->renderImage(viewDevice_, to_kf(pose), 3);
+  downloadView();
+}
+const std::vector<unsigned char>& FusionServer::view(int& rows, int& cols) const
+{
+  rows = viewDevice_.rows();
+  cols = viewDevice_.cols();
+  return viewHost_;
+}
 }  // namespace yak
