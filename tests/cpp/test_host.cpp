@@ -536,8 +536,8 @@ static void test_render_views_against_oracle()
     kinfu(Affine3f::Identity(), pose, pose, d);
   }
   const int rows = p.rows, cols = p.cols;
-  kfusion::cuda::Cloud points;
-  kfusion::cuda::Normals normals;
+  kfusion::cuda::Cloud points(rows, cols);  // the caller allocates (tsdf_volume.cpp:128-145)
+  kfusion::cuda::Normals normals(rows, cols);
   kinfu.tsdf().raycast(pose, p.intr, points, normals);
   std::vector<float> hp((size_t)rows * cols * 4), hn(hp.size());
   points.download(hp.data(), (size_t)cols * 16);
@@ -577,8 +577,8 @@ static void test_render_views_against_oracle()
   }
 
   // the Depth overload re-projects with (fx, fy, cx, fy) as imgproc.cpp:92 does
-  kfusion::cuda::Depth depth_map;
-  kfusion::cuda::Normals normals_d;
+  kfusion::cuda::Depth depth_map(rows, cols);
+  kfusion::cuda::Normals normals_d(rows, cols);
   kinfu.tsdf().raycast(pose, p.intr, depth_map, normals_d);
   std::vector<std::uint16_t> hd((size_t)rows * cols);
   depth_map.download(hd.data(), (size_t)cols * 2);
