@@ -29,7 +29,15 @@ struct IcpState
 
 struct IcpParams
 {
-  const IcpState* state;  // non-null: take the pose from here (and do nothing once status != 0)
+  // device-resident loop (yakhip_icp_estimate).  state != nullptr: the pose comes from there, and nothing
+  // happens once its status != 0.  prev_partial != nullptr as well: *state is the pose BEFORE the previous
+  // linearisation, whose workgroup partials are prev_partial; every workgroup first finishes that
+  // linearisation (reduce, solve, pose update -- all workgroups compute the same bits) and workgroup 0
+  // records the result in *state_out for the next launch.
+  const IcpState* state;
+  IcpState* state_out;
+  const float* prev_partial;
+  int prev_blocks;
   float R[9], t[3];
   float fx, fy, cx, cy;  // level intrinsics, projective_icp.cpp:16-22
   float frows, fcols;    // projective_icp.cpp:200-201
@@ -45,6 +53,206 @@ __device__ __forceinline__ float4 f4_at(const uint8_t* base, uint32_t pitch, int
   return ((const float4*)(base + (size_t)y * pitch))[x];
 }
 
+// Final reduction + solve + pose update of one linearisation, without leaving the device: the
+// reference goes back to the host after every one of its 19 linearisations per frame
+// (projective_icp.cpp:206-229: stream sync, cv::determinant, cv::solve, compose).
+//
+// reduce_partials: wave w of N_WAVES adds the workgroup partials of values w, w + N_WAVES, ... -- lane j
+// takes partials j, j + 64, ... in order, then the butterfly: the sum of a value does not depend on
+// N_WAVES.  Results in LDS; the caller synchronises.
+template <int N_WAVES>
+__device__ __forceinline__ void reduce_partials(const float* partial, int n_blocks, float* sums)
+{
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+  // The partials were written by the previous launch's workgroups on every XCD, so each load here is a
+  // trip to the fabric (about a microsecond): a wave issues the loads of ALL its values, eight deep, before
+  // it adds anything -- one trip for up to 512 workgroups -- and then adds in the fixed order.
+  constexpr int kVals = (kValues + N_WAVES - 1) / N_WAVES, kDeep = 8;
+  float v[kVals];
+#pragma unroll
+  for (int i = 0; i < kVals; ++i)
+    v[i] = 0.f;
+  for (int b0 = lane; b0 < n_blocks; b0 += 64 * kDeep)
+  {
+    float x[kVals][kDeep];
+#pragma unroll
+    for (int i = 0; i < kVals; ++i)
+    {
+      const int k = wave + i * N_WAVES;
+#pragma unroll
+      for (int u = 0; u < kDeep; ++u)
+      {
+        const int b = b0 + 64 * u;
+        x[i][u] = k < kValues && b < n_blocks ? partial[(size_t)k * n_blocks + b] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kDeep; ++u)
+      if (b0 + 64 * u < n_blocks)
+      {
+#pragma unroll
+        for (int i = 0; i < kVals; ++i)
+          v[i] += x[i][u];
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < kVals; ++i)
+  {
+    float r = v[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+      r += __shfl_xor(r, off, 64);
+    const int k = wave + i * N_WAVES;
+    if (lane == 0 && k < kValues)
+      sums[k] = r;
+  }
+}
+
+// 1 / sqrt(x) in double for normal positive x: the hardware estimate and two Newton steps (an ulp or two
+// from the correctly rounded value).  The IEEE division / square-root sequences cost a dozen dependent
+// instructions each and the solve below is one serial chain of them; with 1 / L_ii in hand every division
+// of the factorisation and the substitutions is a multiplication.
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+  double r = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  r = __builtin_fma(r, __builtin_fma(-h * r, r, 0.5), r);
+  return __builtin_fma(r, __builtin_fma(-h * r, r, 0.5), r);
+}
+
+// solve_update: every lane that calls it computes the same thing (a pure function of sums and st).
+// The normal matrix is symmetric positive definite whenever the reference's own checks pass, so a
+// Cholesky factorisation in double gives the solution cv::solve's SVD gives, as long as the SVD would
+// not truncate a singular value.  That is certified, not assumed: lambda_min >= det / (trace / 5)^5
+// (AM-GM on the other five eigenvalues) must exceed OpenCV's cut-off 2 * FLT_EPSILON * trace, and det
+// must be clear of the 1e-15 test; anything else sets status = 2 and the host's LU / SVD path
+// (solve6.hpp) redoes the estimate.
+__device__ __forceinline__ void solve_update(const float* sums, IcpState& st)
+{
+#pragma clang fp contract(fast)  // double precision, nothing here is compared bit for bit: fused multiply-adds halve the chain
+  // StreamHelper::get, projective_icp.cpp:42-61.  Every loop below has constant bounds and is unrolled,
+  // so the 6 x 6 system lives in registers (double precision).
+  double A[6][6], b[6];
+  {
+    int shift = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 7; ++j)
+      {
+        const double value = sums[shift++];
+        if (j == 6)
+          b[i] = value;
+        else
+          A[j][i] = A[i][j] = value;
+      }
+  }
+  double trace = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+    trace += A[i][i];
+
+  // Cholesky A = L L^T (lower triangle in place), det = prod L_ii^2; 1 / L_ii kept for the substitutions
+  double det = 1.0, inv[6];
+  bool spd = trace == trace;
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+  {
+    double d = A[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k)
+      d -= A[j][k] * A[j][k];
+    spd = spd && d > 0.0;
+    const double dd = spd ? d : 1.0;
+    const double rs = fast_rsqrt(dd);
+    double l = dd * rs;
+    l = __builtin_fma(__builtin_fma(-l, l, dd), 0.5 * rs, l);
+    A[j][j] = l;
+    inv[j] = rs;
+    det *= d;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i)
+    {
+      double v = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k)
+        v -= A[i][k] * A[j][k];
+      A[i][j] = v * rs;
+    }
+  }
+  const double m = trace * 0.2;
+  const bool certified = spd && det > 1e-12 && det > 2.0 * 1.1920928955078125e-7 * trace * (m * m * m * m * m) * 4.0;
+  if (!certified)
+  {
+    st.status = 2;
+    return;
+  }
+  double y[6], r[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+  {
+    double v = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k)
+      v -= A[i][k] * y[k];
+    y[i] = v * inv[i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i)
+  {
+    double v = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k)
+      v -= A[k][i] * r[k];
+    r[i] = v * inv[i];
+  }
+
+  // Tinc = Affine3f(rvec, tvec) (Rodrigues), corrected = Tinc * corrected: projective_icp.cpp:227-228,
+  // in the float arithmetic of the host type (include/yak/kfusion/compat/linalg.hpp)
+  const float rv[3] = { (float)r[0], (float)r[1], (float)r[2] };
+  const float tinc[3] = { (float)r[3], (float)r[4], (float)r[5] };
+  float Ri[9] = { 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f };
+  const double th2 = (double)rv[0] * rv[0] + (double)rv[1] * rv[1] + (double)rv[2] * rv[2];
+  if (th2 > 2.220446049250313e-16 * 2.220446049250313e-16)  // theta > DBL_EPSILON
+  {
+    const double inv_th = fast_rsqrt(th2), th = th2 * inv_th;
+    double s, c;
+    sincos(th, &s, &c);
+    const double kx = rv[0] * inv_th, ky = rv[1] * inv_th, kz = rv[2] * inv_th, v = 1.0 - c;
+    Ri[0] = (float)(c + kx * kx * v), Ri[1] = (float)(kx * ky * v - kz * s), Ri[2] = (float)(kx * kz * v + ky * s);
+    Ri[3] = (float)(ky * kx * v + kz * s), Ri[4] = (float)(c + ky * ky * v), Ri[5] = (float)(ky * kz * v - kx * s);
+    Ri[6] = (float)(kz * kx * v - ky * s), Ri[7] = (float)(kz * ky * v + kx * s), Ri[8] = (float)(c + kz * kz * v);
+  }
+  float Rn[9], tn[3];
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr)
+  {
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc)
+      Rn[3 * rr + cc] = Ri[3 * rr + 0] * st.R[0 + cc] + Ri[3 * rr + 1] * st.R[3 + cc] + Ri[3 * rr + 2] * st.R[6 + cc];
+    tn[rr] = (Ri[3 * rr + 0] * st.t[0] + Ri[3 * rr + 1] * st.t[1] + Ri[3 * rr + 2] * st.t[2]) + tinc[rr];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+    st.R[i] = Rn[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    st.t[i] = tn[i];
+  st.iterations += 1;
+}
+
+__device__ __forceinline__ void load_state(const IcpState* src, IcpState& st)  // wave-uniform: scalar loads
+{
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+    st.R[i] = src->R[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    st.t[i] = src->t[i];
+  st.status = src->status;
+  st.iterations = src->iterations;
+}
+
 __global__ __launch_bounds__(256) void icp_accumulate_kernel(const IcpParams p, float* partial, int n_blocks)
 {
   float acc[kValues];
@@ -52,17 +260,50 @@ __global__ __launch_bounds__(256) void icp_accumulate_kernel(const IcpParams p, 
   for (int k = 0; k < kValues; ++k)
     acc[k] = 0.f;
 
-  float R[9], t[3];
-  if (p.state)  // wave-uniform: scalar loads
+  // The four pixels of a lane are independent until their sums meet, and the kernel is latency-bound (one
+  // or two waves per SIMD, each pixel a chain load -> project -> gather): all four current-map loads go
+  // out together, then all four gathers, then the arithmetic -- pixel by pixel in the old order, so the
+  // sums are bit for bit what the one-pixel-at-a-time loop gave.  The current-map loads do not depend on
+  // the pose, so they are issued before the pose is worked out (device-resident loop) and fly meanwhile.
+  const int n_pixels = p.rows * p.cols;
+  const int base = (int)blockIdx.x * (256 * kPixelsPerLane) + (int)threadIdx.x;
+  bool live[kPixelsPerLane];
+  float4 s0[kPixelsPerLane], nc[kPixelsPerLane], d[kPixelsPerLane], nd[kPixelsPerLane];
+#pragma unroll
+  for (int i = 0; i < kPixelsPerLane; ++i)
   {
-    if (p.state->status != 0)
+    const int pix = base + i * 256;
+    live[i] = pix < n_pixels;
+    const int pc = live[i] ? pix : n_pixels - 1;  // n_pixels >= 1 (launchers); a dead lane re-reads the last pixel
+    const int yr = pc / p.cols, x = pc - yr * p.cols, y = yr + p.row0;
+    s0[i] = f4_at(p.vcurr, p.vcurr_pitch, y, x);
+    nc[i] = f4_at(p.ncurr, p.ncurr_pitch, y, x);
+  }
+  float R[9], t[3];
+  if (p.state)
+  {
+    IcpState st;
+    load_state(p.state, st);
+    if (p.prev_partial)
+    {
+      // not gated by the status: the partial loads then leave together with the state's scalar loads (one
+      // trip to the fabric instead of two); after a stop they read stale scratch, which nobody uses
+      __shared__ float prev_sums[kValues];
+      reduce_partials<4>(p.prev_partial, p.prev_blocks, prev_sums);
+      __syncthreads();
+      if (st.status == 0)
+        solve_update(prev_sums, st);
+      if (blockIdx.x == 0 && threadIdx.x == 0)
+        *p.state_out = st;
+    }
+    if (st.status != 0)
       return;
 #pragma unroll
     for (int i = 0; i < 9; ++i)
-      R[i] = p.state->R[i];
+      R[i] = st.R[i];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
-      t[i] = p.state->t[i];
+      t[i] = st.t[i];
   }
   else
   {
@@ -74,70 +315,72 @@ __global__ __launch_bounds__(256) void icp_accumulate_kernel(const IcpParams p, 
       t[i] = p.t[i];
   }
 
-  const int n_pixels = p.rows * p.cols;
-  const int base = (int)blockIdx.x * (256 * kPixelsPerLane) + (int)threadIdx.x;
+  int code[kPixelsPerLane];
+  float sx[kPixelsPerLane], sy[kPixelsPerLane], sz[kPixelsPerLane];
+#pragma unroll
   for (int i = 0; i < kPixelsPerLane; ++i)
   {
-    const int pix = base + i * 256;
-    if (pix >= n_pixels)
-      break;
-    const int yr = pix / p.cols, x = pix - yr * p.cols, y = yr + p.row0;
-
-    // find_coresp, proj_icp.cu:74-102
-    int code = 0;
-    float row[7];
-    const float4 s0 = f4_at(p.vcurr, p.vcurr_pitch, y, x);
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    float4 d = make_float4(0.f, 0.f, 0.f, 0.f), nd = d;
-    if (s0.x != s0.x)
-      code = 40;
+    // find_coresp, proj_icp.cu:74-102, up to the fetch of the destination point
+    code[i] = 0;
+    sx[i] = sy[i] = sz[i] = 0.f;
+    int px = 0, py = 0;
+    if (s0[i].x != s0[i].x)
+      code[i] = 40;
     else
     {
-      sx = dot3(R[0], R[1], R[2], s0.x, s0.y, s0.z) + t[0];
-      sy = dot3(R[3], R[4], R[5], s0.x, s0.y, s0.z) + t[1];
-      sz = dot3(R[6], R[7], R[8], s0.x, s0.y, s0.z) + t[2];
-      if (sz <= 0.f)
-        code = 80;
+      sx[i] = dot3(R[0], R[1], R[2], s0[i].x, s0[i].y, s0[i].z) + t[0];
+      sy[i] = dot3(R[3], R[4], R[5], s0[i].x, s0[i].y, s0[i].z) + t[1];
+      sz[i] = dot3(R[6], R[7], R[8], s0[i].x, s0[i].y, s0[i].z) + t[2];
+      if (sz[i] <= 0.f)
+        code[i] = 80;
       else
       {
-        const float coox = __builtin_fmaf(p.fx, sx / sz, p.cx), cooy = __builtin_fmaf(p.fy, sy / sz, p.cy);
+        const float coox = __builtin_fmaf(p.fx, sx[i] / sz[i], p.cx), cooy = __builtin_fmaf(p.fy, sy[i] / sz[i], p.cy);
         if (!(coox >= 0.f && cooy >= 0.f && coox < p.fcols && cooy < p.frows))
-          code = 80;
+          code[i] = 80;
+        else
+          px = (int)__builtin_floorf(coox), py = (int)__builtin_floorf(cooy);  // point-filtered fetch
+      }
+    }
+    d[i] = f4_at(p.vprev, p.vprev_pitch, py, px);  // pixel (0, 0) for a rejected one: read and ignored
+    nd[i] = f4_at(p.nprev, p.nprev_pitch, py, px);
+  }
+#pragma unroll
+  for (int i = 0; i < kPixelsPerLane; ++i)
+  {
+    if (!live[i])
+      break;
+    int c = code[i];
+    if (c == 0)
+    {
+      if (d[i].x != d[i].x)
+        c = 120;
+      else
+      {
+        const float ex = sx[i] - d[i].x, ey = sy[i] - d[i].y, ez = sz[i] - d[i].z;
+        if (dot3(ex, ey, ez, ex, ey, ez) > p.dist2_thres)
+          c = 160;
         else
         {
-          const int px = (int)__builtin_floorf(coox), py = (int)__builtin_floorf(cooy);  // point-filtered fetch
-          d = f4_at(p.vprev, p.vprev_pitch, py, px);
-          if (d.x != d.x)
-            code = 120;
-          else
-          {
-            const float ex = sx - d.x, ey = sy - d.y, ez = sz - d.z;
-            if (dot3(ex, ey, ez, ex, ey, ez) > p.dist2_thres)
-              code = 160;
-            else
-            {
-              const float4 nc = f4_at(p.ncurr, p.ncurr_pitch, y, x);
-              const float nsx = dot3(R[0], R[1], R[2], nc.x, nc.y, nc.z);
-              const float nsy = dot3(R[3], R[4], R[5], nc.x, nc.y, nc.z);
-              const float nsz = dot3(R[6], R[7], R[8], nc.x, nc.y, nc.z);
-              nd = f4_at(p.nprev, p.nprev_pitch, py, px);
-              const float cosine = __builtin_fabsf(dot3(nsx, nsy, nsz, nd.x, nd.y, nd.z));
-              if (cosine < p.min_cosine)
-                code = 200;
-            }
-          }
+          const float nsx = dot3(R[0], R[1], R[2], nc[i].x, nc[i].y, nc[i].z);
+          const float nsy = dot3(R[3], R[4], R[5], nc[i].x, nc[i].y, nc[i].z);
+          const float nsz = dot3(R[6], R[7], R[8], nc[i].x, nc[i].y, nc[i].z);
+          const float cosine = __builtin_fabsf(dot3(nsx, nsy, nsz, nd[i].x, nd[i].y, nd[i].z));
+          if (cosine < p.min_cosine)
+            c = 200;
         }
       }
     }
 
-    if (code == 0)
+    if (c == 0)
     {
       // proj_icp.cu:354-359  row = [cross(s, n), n, dot(n, d - s)]
-      row[0] = sy * nd.z - sz * nd.y;
-      row[1] = sz * nd.x - sx * nd.z;
-      row[2] = sx * nd.y - sy * nd.x;
-      row[3] = nd.x, row[4] = nd.y, row[5] = nd.z;
-      row[6] = dot3(nd.x, nd.y, nd.z, d.x - sx, d.y - sy, d.z - sz);
+      float row[7];
+      row[0] = sy[i] * nd[i].z - sz[i] * nd[i].y;
+      row[1] = sz[i] * nd[i].x - sx[i] * nd[i].z;
+      row[2] = sx[i] * nd[i].y - sy[i] * nd[i].x;
+      row[3] = nd[i].x, row[4] = nd[i].y, row[5] = nd[i].z;
+      row[6] = dot3(nd[i].x, nd[i].y, nd[i].z, d[i].x - sx[i], d[i].y - sy[i], d[i].z - sz[i]);
       int k = 0;
 #pragma unroll
       for (int a = 0; a < 6; ++a)
@@ -148,11 +391,11 @@ __global__ __launch_bounds__(256) void icp_accumulate_kernel(const IcpParams p, 
     }
     else
     {
-      acc[28] += code == 40 ? 1.f : 0.f;
-      acc[29] += code == 80 ? 1.f : 0.f;
-      acc[30] += code == 120 ? 1.f : 0.f;
-      acc[31] += code == 160 ? 1.f : 0.f;
-      acc[32] += code == 200 ? 1.f : 0.f;
+      acc[28] += c == 40 ? 1.f : 0.f;
+      acc[29] += c == 80 ? 1.f : 0.f;
+      acc[30] += c == 120 ? 1.f : 0.f;
+      acc[31] += c == 160 ? 1.f : 0.f;
+      acc[32] += c == 200 ? 1.f : 0.f;
     }
   }
 
@@ -195,141 +438,20 @@ __global__ __launch_bounds__(64) void icp_final_kernel(const float* partial, int
   if (threadIdx.x == 0)
     out[k] = v;
 }
-// Final reduction + solve + pose update of one linearisation, without leaving the device: the
-// reference goes back to the host after every one of its 19 linearisations per frame
-// (projective_icp.cpp:206-229: stream sync, cv::determinant, cv::solve, compose).
-// One workgroup: wave w adds the workgroup partials of values w, w + 16, w + 32 in a fixed order; then
-// one lane solves the 6 x 6 system.  The normal matrix is symmetric positive definite whenever the
-// reference's own checks pass, so a Cholesky factorisation in double gives the solution cv::solve's SVD
-// gives, as long as the SVD would not truncate a singular value.  That is certified, not assumed:
-// lambda_min >= det / (trace / 5)^5 (AM-GM on the other five eigenvalues) must exceed OpenCV's cut-off
-// 2 * FLT_EPSILON * trace, and det must be clear of the 1e-15 test; anything else sets status = 2 and the
-// host's LU / SVD path (solve6.hpp) redoes the estimate.
-__global__ __launch_bounds__(1024) void icp_solve_kernel(const float* partial, int n_blocks, IcpState* st, float* sums_out)
+// The last linearisation of a device-resident estimate has no accumulate launch behind it to finish it:
+// one workgroup does (state_in, partial) -> state_out.
+__global__ __launch_bounds__(1024) void icp_solve_kernel(const float* partial, int n_blocks, const IcpState* state_in,
+                                                         IcpState* state_out)
 {
   __shared__ float sums[kValues];
-  if (st->status != 0)
-    return;
-  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-  for (int k = wave; k < kValues; k += 16)
-  {
-    float v = 0.f;
-    for (int b = lane; b < n_blocks; b += 64)
-      v += partial[(size_t)k * n_blocks + b];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1)
-      v += __shfl_xor(v, off, 64);
-    if (lane == 0)
-      sums[k] = v;
-  }
+  IcpState st;
+  load_state(state_in, st);
+  reduce_partials<16>(partial, n_blocks, sums);
   __syncthreads();
-  if (threadIdx.x != 0)
-    return;
-  for (int k = 0; k < kValues; ++k)
-    sums_out[k] = sums[k];
-
-  // StreamHelper::get, projective_icp.cpp:42-61.  Every loop below has constant bounds and is unrolled,
-  // so the 6 x 6 system lives in registers (one lane, double precision).
-  double A[6][6], b[6];
-  {
-    int shift = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = i; j < 7; ++j)
-      {
-        const double value = sums[shift++];
-        if (j == 6)
-          b[i] = value;
-        else
-          A[j][i] = A[i][j] = value;
-      }
-  }
-  double trace = 0.0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-    trace += A[i][i];
-
-  // Cholesky A = L L^T (lower triangle in place), det = prod L_ii^2
-  double det = 1.0;
-  bool spd = trace == trace;
-#pragma unroll
-  for (int j = 0; j < 6; ++j)
-  {
-    double d = A[j][j];
-#pragma unroll
-    for (int k = 0; k < j; ++k)
-      d -= A[j][k] * A[j][k];
-    spd = spd && d > 0.0;
-    const double l = sqrt(spd ? d : 1.0);
-    A[j][j] = l;
-    det *= d;
-#pragma unroll
-    for (int i = j + 1; i < 6; ++i)
-    {
-      double v = A[i][j];
-#pragma unroll
-      for (int k = 0; k < j; ++k)
-        v -= A[i][k] * A[j][k];
-      A[i][j] = v / l;
-    }
-  }
-  const double m = trace / 5.0;
-  const bool certified = spd && det > 1e-12 && det > 2.0 * 1.1920928955078125e-7 * trace * (m * m * m * m * m) * 4.0;
-  if (!certified)
-  {
-    st->status = 2;
-    return;
-  }
-  double y[6], r[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-  {
-    double v = b[i];
-#pragma unroll
-    for (int k = 0; k < i; ++k)
-      v -= A[i][k] * y[k];
-    y[i] = v / A[i][i];
-  }
-#pragma unroll
-  for (int i = 5; i >= 0; --i)
-  {
-    double v = y[i];
-#pragma unroll
-    for (int k = i + 1; k < 6; ++k)
-      v -= A[k][i] * r[k];
-    r[i] = v / A[i][i];
-  }
-
-  // Tinc = Affine3f(rvec, tvec) (Rodrigues), corrected = Tinc * corrected: projective_icp.cpp:227-228,
-  // in the float arithmetic of the host type (include/yak/kfusion/compat/linalg.hpp)
-  const float rv[3] = { (float)r[0], (float)r[1], (float)r[2] };
-  const float tinc[3] = { (float)r[3], (float)r[4], (float)r[5] };
-  float Ri[9] = { 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f };
-  const double th = sqrt((double)rv[0] * rv[0] + (double)rv[1] * rv[1] + (double)rv[2] * rv[2]);
-  if (th > 2.220446049250313e-16)
-  {
-    const double kx = rv[0] / th, ky = rv[1] / th, kz = rv[2] / th, c = cos(th), s = sin(th), v = 1.0 - c;
-    Ri[0] = (float)(c + kx * kx * v), Ri[1] = (float)(kx * ky * v - kz * s), Ri[2] = (float)(kx * kz * v + ky * s);
-    Ri[3] = (float)(ky * kx * v + kz * s), Ri[4] = (float)(c + ky * ky * v), Ri[5] = (float)(ky * kz * v - kx * s);
-    Ri[6] = (float)(kz * kx * v - ky * s), Ri[7] = (float)(kz * ky * v + kx * s), Ri[8] = (float)(c + kz * kz * v);
-  }
-  float Rn[9], tn[3];
-#pragma unroll
-  for (int rr = 0; rr < 3; ++rr)
-  {
-#pragma unroll
-    for (int cc = 0; cc < 3; ++cc)
-      Rn[3 * rr + cc] = Ri[3 * rr + 0] * st->R[0 + cc] + Ri[3 * rr + 1] * st->R[3 + cc] + Ri[3 * rr + 2] * st->R[6 + cc];
-    tn[rr] = (Ri[3 * rr + 0] * st->t[0] + Ri[3 * rr + 1] * st->t[1] + Ri[3 * rr + 2] * st->t[2]) + tinc[rr];
-  }
-#pragma unroll
-  for (int i = 0; i < 9; ++i)
-    st->R[i] = Rn[i];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-    st->t[i] = tn[i];
-  st->iterations += 1;
+  if (st.status == 0)
+    solve_update(sums, st);
+  if (threadIdx.x == 0)
+    *state_out = st;
 }
 }  // namespace
 
@@ -342,7 +464,7 @@ int launch_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], c
                           int row_begin, int row_end, float* sums_dev)
 {
   IcpParams p;
-  p.state = nullptr;
+  p.state = nullptr, p.state_out = nullptr, p.prev_partial = nullptr, p.prev_blocks = 0;
   for (int i = 0; i < 9; ++i)
     p.R[i] = R[i];
   for (int i = 0; i < 3; ++i)
@@ -409,16 +531,25 @@ static int icp_scratch(yakhip_ctx* ctx, size_t need)
 }
 
 // The whole coarse-to-fine schedule of ProjectiveICP::estimateTransform (projective_icp.cpp:175-232)
-// enqueued back to back: per linearisation one accumulate launch and one reduce+solve launch, the pose
-// handed from one to the next in device memory; the host waits once, at the end.
-// (Folding the reduce+solve into the accumulate launch -- last workgroup by ticket -- was measured and is
-// slower, 0.52 vs 0.34 ms per frame: the device-scope release/acquire fences every workgroup then needs
-// write back and invalidate the XCD's L2, which costs more than the second launch.)
+// enqueued back to back, ONE launch per linearisation: launch j first finishes linearisation j - 1 (every
+// workgroup reduces its partials and solves -- redundant, identical, and a few microseconds of latency
+// that a separate launch would also have cost, without that launch's gap), then accumulates its own.  The
+// pose travels through a chain of state slots (launch j reads slot j - 1 and workgroup 0 writes slot j),
+// the partials through two alternating buffers, so no launch writes what a workgroup of the same launch
+// reads.  A single-workgroup launch finishes the last linearisation; the host waits once, at the end.
+// Measured per frame at 640 x 480, 10/5/4 linearisations: 0.34 ms with a reduce+solve launch behind every
+// accumulate launch (that launch alone took 13 us: five dependent trips to the fabric for the partials and
+// an IEEE-division Cholesky on one lane), 0.28 ms with this schedule; a launch now takes 11-13 us whatever
+// the level -- a chain of state + partials load, solve, gather, butterfly, store -- and the gaps 1-2 us.
+// (Folding the reduce+solve into the SAME accumulate launch -- last workgroup by ticket -- was measured and is
+// slower, 0.52 ms: the device-scope release/acquire fences every workgroup then needs write back and
+// invalidate the XCD's L2, which costs more than a launch.)
 int launch_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], float dist_thres,
                         float angle_thres, const yakhip_icp_level* levels, int n_levels, float R_out[9], float t_out[3],
                         int* status_out, int* iterations_out)
 {
   int max_blocks = 1;
+  long long n_launches = 0;
   for (int l = 0; l < n_levels; ++l)
   {
     const long long n_pixels = (long long)levels[l].rows * levels[l].cols;
@@ -427,56 +558,70 @@ int launch_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], con
     const int nb = (int)((n_pixels + 256 * kPixelsPerLane - 1) / (256 * kPixelsPerLane));
     if (nb > max_blocks)
       max_blocks = nb;
+    n_launches += levels[l].iterations > 0 ? levels[l].iterations : 0;
   }
-  const size_t partial_bytes = ((size_t)max_blocks * kValues + kValues) * sizeof(float);
-  const size_t state_off = (partial_bytes + 255u) & ~(size_t)255u;
-  int rc = icp_scratch(ctx, state_off + sizeof(IcpState));
+  if (n_launches > 100000)
+    return fail(YAKHIP_ERANGE, "icp: more than 100000 linearisations");
+  // scratch: partials A | partials B | state slots 0 .. n_launches
+  const size_t partial_bytes = ((size_t)max_blocks * kValues * sizeof(float) + 255u) & ~(size_t)255u;
+  int rc = icp_scratch(ctx, 2 * partial_bytes + ((size_t)n_launches + 1) * sizeof(IcpState));
   if (rc != 0)
     return rc;
-  float* partial = (float*)ctx->icp_scratch;
-  float* sums_dev = partial + (size_t)max_blocks * kValues;
-  IcpState* st = (IcpState*)((char*)ctx->icp_scratch + state_off);
+  float* partial[2] = { (float*)ctx->icp_scratch, (float*)((char*)ctx->icp_scratch + partial_bytes) };
+  IcpState* slots = (IcpState*)((char*)ctx->icp_scratch + 2 * partial_bytes);
 
-  IcpState init;
-  for (int i = 0; i < 9; ++i)
-    init.R[i] = R[i];
-  for (int i = 0; i < 3; ++i)
-    init.t[i] = t[i];
-  init.status = 0;
-  init.iterations = 0;
   IcpState* host = (IcpState*)ctx->icp_pinned;
-  *host = init;
-  YAKHIP_TRY(hipMemcpyAsync(st, host, sizeof(IcpState), hipMemcpyHostToDevice, ctx->stream));
-
-  for (int l = n_levels - 1; l >= 0; --l)
+  for (int i = 0; i < 9; ++i)
+    host->R[i] = R[i];
+  for (int i = 0; i < 3; ++i)
+    host->t[i] = t[i];
+  host->status = 0;
+  host->iterations = 0;
+  if (n_launches > 0)
   {
-    const yakhip_icp_level& L = levels[l];
-    IcpParams p;
-    p.state = st;
-    for (int i = 0; i < 9; ++i)
-      p.R[i] = 0.f;
-    for (int i = 0; i < 3; ++i)
-      p.t[i] = 0.f;
-    const int div = 1 << l;  // projective_icp.cpp:16-22
-    p.fx = intr[0] / div, p.fy = intr[1] / div, p.cx = intr[2] / div, p.cy = intr[3] / div;
-    p.frows = (float)L.rows, p.fcols = (float)L.cols;
-    p.min_cosine = (float)cos((double)angle_thres);
-    p.dist2_thres = dist_thres * dist_thres;
-    p.vcurr = (const uint8_t*)L.vcurr, p.ncurr = (const uint8_t*)L.ncurr;
-    p.vprev = (const uint8_t*)L.vprev, p.nprev = (const uint8_t*)L.nprev;
-    p.vcurr_pitch = (uint32_t)L.vcurr_pitch, p.ncurr_pitch = (uint32_t)L.ncurr_pitch;
-    p.vprev_pitch = (uint32_t)L.vprev_pitch, p.nprev_pitch = (uint32_t)L.nprev_pitch;
-    p.rows = L.rows, p.cols = L.cols, p.row0 = 0;
-    const int n_blocks = (int)(((long long)L.rows * L.cols + 256 * kPixelsPerLane - 1) / (256 * kPixelsPerLane));
-    for (int it = 0; it < L.iterations; ++it)
+    YAKHIP_TRY(hipMemcpyAsync(&slots[0], host, sizeof(IcpState), hipMemcpyHostToDevice, ctx->stream));
+    int j = 0, prev_blocks = 0;
+    for (int l = n_levels - 1; l >= 0; --l)
     {
-      hipLaunchKernelGGL(icp_accumulate_kernel, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, p, partial, n_blocks);
-      hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(1024), 0, ctx->stream, partial, n_blocks, st, sums_dev);
+      const yakhip_icp_level& L = levels[l];
+      if (L.iterations <= 0)
+        continue;
+      IcpParams p;
+      for (int i = 0; i < 9; ++i)
+        p.R[i] = 0.f;
+      for (int i = 0; i < 3; ++i)
+        p.t[i] = 0.f;
+      const int div = 1 << l;  // projective_icp.cpp:16-22
+      p.fx = intr[0] / div, p.fy = intr[1] / div, p.cx = intr[2] / div, p.cy = intr[3] / div;
+      p.frows = (float)L.rows, p.fcols = (float)L.cols;
+      p.min_cosine = (float)cos((double)angle_thres);
+      p.dist2_thres = dist_thres * dist_thres;
+      p.vcurr = (const uint8_t*)L.vcurr, p.ncurr = (const uint8_t*)L.ncurr;
+      p.vprev = (const uint8_t*)L.vprev, p.nprev = (const uint8_t*)L.nprev;
+      p.vcurr_pitch = (uint32_t)L.vcurr_pitch, p.ncurr_pitch = (uint32_t)L.ncurr_pitch;
+      p.vprev_pitch = (uint32_t)L.vprev_pitch, p.nprev_pitch = (uint32_t)L.nprev_pitch;
+      p.rows = L.rows, p.cols = L.cols, p.row0 = 0;
+      const int n_blocks = (int)(((long long)L.rows * L.cols + 256 * kPixelsPerLane - 1) / (256 * kPixelsPerLane));
+      for (int it = 0; it < L.iterations; ++it, ++j)
+      {
+        // launch 0 takes slot 0 as it is; launch j > 0 turns slot j - 1 and launch j - 1's partials into slot j
+        p.state = j == 0 ? &slots[0] : &slots[j - 1];
+        p.state_out = &slots[j];
+        p.prev_partial = j == 0 ? nullptr : partial[(j - 1) & 1];
+        p.prev_blocks = prev_blocks;
+        hipLaunchKernelGGL(icp_accumulate_kernel, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, p, partial[j & 1],
+                           n_blocks);
+        prev_blocks = n_blocks;
+      }
+      YAKHIP_TRY(hipGetLastError());
     }
+    // j == n_launches: the last launch read slot max(j - 2, 0) and (for j > 1) wrote slot j - 1
+    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(1024), 0, ctx->stream, partial[(j - 1) & 1], prev_blocks,
+                       &slots[j - 1], &slots[j]);
     YAKHIP_TRY(hipGetLastError());
+    YAKHIP_TRY(hipMemcpyAsync(host, &slots[j], sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
+    YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
   }
-  YAKHIP_TRY(hipMemcpyAsync(host, st, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
-  YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < 9; ++i)
     R_out[i] = host->R[i];
   for (int i = 0; i < 3; ++i)
