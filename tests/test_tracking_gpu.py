@@ -345,3 +345,26 @@ def test_icp_estimate_degenerate_inputs_take_the_host_path(gpu_ctx):
     # level index 0 with quarter-size maps: pass the matching intrinsics as "level 0"
     Rd, td, ok = gpu_ctx.icp_estimate(np.eye(3).reshape(-1), np.zeros(3), tuple(v / 4 for v in synth.INTR), 0.1, 0.5, lv)
     assert (not ok) or (np.isfinite(Rd).all() and np.isfinite(td).all())
+
+
+def test_icp_estimate_schedule_edges(gpu_ctx):
+    """The launch chain at its ends: no linearisation at all (the start pose comes back untouched), exactly
+    one (launch 0 + the closing solve), two (the first launch that finishes its predecessor)."""
+    prev, curr = level_maps(60, 1), level_maps(62, 1)
+    dev = {1: [dev_f4(a) for a in (curr[0], curr[1], prev[0], prev[1])]}
+    rows, cols = curr[0].shape[:2]
+    d = dev[1]
+    R0 = np.float32([[0.9998, 0, 0.02], [0, 1, 0], [-0.02, 0, 0.9998]])
+    t0 = np.float32([0.01, -0.02, 0.03])
+
+    def lv(n):  # pyramid level 1 holds the maps, level 0 is present but idle
+        return [(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 16, 1, 1, 0),
+                (d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[0].stride(0) * 4, rows, cols, n)]
+
+    Rd, td, ok = gpu_ctx.icp_estimate(R0.reshape(-1), t0, synth.INTR, 0.1, math.radians(30.0), lv(0))
+    assert ok and np.array_equal(np.float32(Rd).reshape(3, 3), R0) and np.array_equal(np.float32(td), t0)
+    for n in (1, 2, 3):
+        Rd, td, ok = gpu_ctx.icp_estimate(np.eye(3).reshape(-1), np.zeros(3), synth.INTR, 0.1, math.radians(30.0), lv(n))
+        Rh, th, okh = _gn_loop_python(gpu_ctx, dev, {1: (rows, cols)}, ((1, n),), np.eye(3), np.zeros(3))
+        assert ok and okh
+        assert np.abs(np.array(Rd).reshape(3, 3) - Rh).max() < 1e-5 and np.abs(np.array(td) - th).max() < 1e-5, n
