@@ -32,6 +32,10 @@ public:
   bool reset();
   bool resetWithNewParams(const kfusion::KinFuParams& params);
   yak::TSDFContainer downloadTSDF();
+  /** The inverse of downloadTSDF (no counterpart in the reference, whose only way in is fuse()): replaces the
+   *  device volume by `volume`, e.g. to resume a fusion that was saved.  Returns false, touching nothing,
+   *  if the dimensions differ from the server's volume.  Tracking continues from the poses it had. */
+  bool uploadTSDF(const yak::TSDFContainer& volume);
   /** Renders the tracker's current model view (Phong | normal colours, rows x 2 cols) and downloads it
    *  (yak_server.cpp:100-104); the reference then shows it in a window. */
   void display();

@@ -114,6 +114,12 @@ int yakhip_upload_2d(yakhip_ctx* ctx, void* dst_dev, size_t dst_pitch, const voi
 int yakhip_download_2d(yakhip_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_dev, size_t src_pitch,
                        size_t width_bytes, size_t rows);
 
+/* Device-to-device, blocking: replaces the cudaMemcpy / cudaMemcpy2D of DeviceMemory[2D]::copyTo
+ * (device_memory.cpp:105-114, 233-242).  Ranges must not overlap. */
+int yakhip_copy(yakhip_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
+int yakhip_copy_2d(yakhip_ctx* ctx, void* dst_dev, size_t dst_pitch, const void* src_dev, size_t src_pitch,
+                   size_t width_bytes, size_t rows);
+
 /* ---- hot path ----------------------------------------------------------------------------- */
 
 /* Replaces kfusion::device::clear_volume (internal.hpp:125; yak/src/cuda/tsdf_volume.cu:14-40):

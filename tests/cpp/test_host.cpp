@@ -279,12 +279,22 @@ static void test_fusion_server_against_oracle()
     EXPECT(diff == 0);
     EXPECT(f == 0 || touched > 1000);
   }
+  const yak::TSDFContainer saved = server.downloadTSDF();
   EXPECT(server.reset());
   const yak::TSDFContainer cleared = server.downloadTSDF();
   size_t nz = 0;
   for (size_t i = 0; i < cleared.size64(); ++i)
     nz += cleared.data()[i] != 0;
   EXPECT(nz == 0);
+  // uploadTSDF puts a saved volume back, word for word; a container of another size is refused
+  EXPECT(server.uploadTSDF(saved));
+  const yak::TSDFContainer back = server.downloadTSDF();
+  EXPECT(back.size64() == saved.size64() && std::memcmp(back.data(), saved.data(), saved.size64() * 4) == 0);
+  EXPECT(!server.uploadTSDF(yak::TSDFContainer(8, 8, 8)));
+  // DeviceMemory::copyTo is a device-to-device copy into memory of its own
+  kfusion::cuda::CudaData copy;
+  probe.tsdf().data().copyTo(copy);
+  EXPECT(copy.sizeBytes() == probe.tsdf().data().sizeBytes() && copy.ptr<void>() != probe.tsdf().data().ptr<void>());
 }
 
 // camera -> volume pose looking from `eye` at `target`, +y down (the convention of the depth frames)

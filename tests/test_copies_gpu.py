@@ -56,3 +56,19 @@ def test_copy_argument_checks(gpu_ctx):
         gpu_ctx.download(host.ctypes.data, 0, 8)
     with pytest.raises(capi.YakHipError):
         gpu_ctx.upload_2d(dev.data_ptr(), 4, host.ctypes.data, 8, 8, 2)       # row wider than the device pitch
+
+
+def test_device_to_device_copies(gpu_ctx):
+    """yakhip_copy / yakhip_copy_2d (DeviceMemory[2D]::copyTo, device_memory.cpp:105-114, 233-242)."""
+    src = torch.arange(100003, dtype=torch.int32, device="cuda")
+    dst = torch.zeros_like(src)
+    gpu_ctx.copy(dst.data_ptr(), src.data_ptr(), src.numel() * 4)
+    assert torch.equal(dst, src)
+    a = torch.arange(37 * 64, dtype=torch.int16, device="cuda").reshape(37, 64)
+    b = torch.full((37, 80), -1, dtype=torch.int16, device="cuda")
+    gpu_ctx.copy_2d(b.data_ptr(), 160, a.data_ptr(), 128, 53 * 2, 37)         # 53 of 64 columns into a wider image
+    assert torch.equal(b[:, :53], a[:, :53]) and (b[:, 53:] == -1).all()
+    from yak_amd.capi import YakHipError
+    with pytest.raises(YakHipError):
+        gpu_ctx.copy_2d(b.data_ptr(), 100, a.data_ptr(), 128, 53 * 2, 37)     # pitch smaller than a row
+    gpu_ctx.copy(dst.data_ptr(), src.data_ptr(), 0)                             # nothing to do

@@ -15,7 +15,7 @@ EXPORTS = [
     "yakhip_device_count", "yakhip_device_name", "yakhip_last_error", "yakhip_ctx_set_option",
     "yakhip_ctx_kernel_time", "yakhip_selftest_division",
     "yakhip_malloc", "yakhip_malloc_pitch", "yakhip_free", "yakhip_upload", "yakhip_download",
-    "yakhip_upload_2d", "yakhip_download_2d",
+    "yakhip_upload_2d", "yakhip_download_2d", "yakhip_copy", "yakhip_copy_2d",
     "yakhip_clear_volume", "yakhip_compute_dists", "yakhip_integrate", "yakhip_integrate_batch",
     "yakhip_raycast_points", "yakhip_raycast_depth", "yakhip_raycast_slab", "yakhip_raycast_resolve", "yakhip_raycast_halo",
     "yakhip_bilateral_filter", "yakhip_truncate_depth", "yakhip_depth_pyramid", "yakhip_compute_points_normals",
@@ -99,6 +99,8 @@ def load():
         "yakhip_download": [vp, vp, vp, sz],
         "yakhip_upload_2d": [vp, vp, sz, vp, sz, sz, sz],
         "yakhip_download_2d": [vp, vp, sz, vp, sz, sz, sz],
+        "yakhip_copy": [vp, vp, vp, sz],
+        "yakhip_copy_2d": [vp, vp, sz, vp, sz, sz, sz],
         "yakhip_clear_volume": [vp, volp],
         "yakhip_compute_dists": [vp, vp, sz, vp, sz, i, i, fp],
         "yakhip_integrate": [vp, volp, vp, sz, i, i, fp, fp, fp],
@@ -235,6 +237,12 @@ class Context:
     def download_2d(self, dst, dst_pitch, src_ptr, src_pitch, width_bytes, rows):
         _chk(load().yakhip_download_2d(self._h, C.c_void_p(dst), dst_pitch, C.c_void_p(src_ptr), src_pitch, width_bytes,
                                        rows))
+
+    def copy(self, dst_ptr, src_ptr, nbytes):
+        _chk(load().yakhip_copy(self._h, C.c_void_p(dst_ptr), C.c_void_p(src_ptr), nbytes))
+
+    def copy_2d(self, dst_ptr, dst_pitch, src_ptr, src_pitch, width_bytes, rows):
+        _chk(load().yakhip_copy_2d(self._h, C.c_void_p(dst_ptr), dst_pitch, C.c_void_p(src_ptr), src_pitch, width_bytes, rows))
 
     def raycast_points(self, vol, R, t, Rinv, intr, points_ptr, points_pitch, normals_ptr, normals_pitch, rows, cols,
                        step_factor=0.75, gradient_delta_factor=0.5):

@@ -462,6 +462,36 @@ int yakhip_download(yakhip_ctx* ctx, void* dst_host, const void* src_dev, size_t
   return staged_copy(ctx, (uint8_t*)const_cast<void*>(src_dev), bytes, (uint8_t*)dst_host, bytes, bytes, 1, false);
 }
 
+int yakhip_copy(yakhip_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!dst_dev || !src_dev)
+    return fail(YAKHIP_EINVAL, "copy: null pointer");
+  if (bytes == 0)
+    return 0;
+  YAKHIP_TRY(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+int yakhip_copy_2d(yakhip_ctx* ctx, void* dst_dev, size_t dst_pitch, const void* src_dev, size_t src_pitch,
+                   size_t width_bytes, size_t rows)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!dst_dev || !src_dev)
+    return fail(YAKHIP_EINVAL, "copy_2d: null pointer");
+  if (dst_pitch < width_bytes || src_pitch < width_bytes)
+    return fail(YAKHIP_EINVAL, "copy_2d: pitch smaller than a row");
+  if (width_bytes == 0 || rows == 0)
+    return 0;
+  YAKHIP_TRY(hipMemcpy2DAsync(dst_dev, dst_pitch, src_dev, src_pitch, width_bytes, rows, hipMemcpyDeviceToDevice,
+                              ctx->stream));
+  return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
 int yakhip_upload_2d(yakhip_ctx* ctx, void* dst_dev, size_t dst_pitch, const void* src_host, size_t src_pitch,
                      size_t width_bytes, size_t rows)
 {

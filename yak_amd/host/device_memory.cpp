@@ -120,11 +120,7 @@ void DeviceMemory::copyTo(DeviceMemory& other) const
     return;
   }
   other.create(sizeBytes_);
-  // device-to-device through the stream: download/upload would bounce through the host
-  std::shared_ptr<void> keep = other.owner_;
-  std::vector<char> tmp(sizeBytes_);
-  YAK_CHECK(yakhip_download(context(), tmp.data(), data_, sizeBytes_));
-  YAK_CHECK(yakhip_upload(context(), other.data_, tmp.data(), sizeBytes_));
+  YAK_CHECK(yakhip_copy(context(), other.data_, data_, sizeBytes_));  // device_memory.cpp:112
 }
 void DeviceMemory::upload(const void* host_ptr_arg, size_t sizeBytes_arg)
 {
@@ -202,9 +198,7 @@ void DeviceMemory2D::copyTo(DeviceMemory2D& other) const
     return;
   }
   other.create(rows_, colsBytes_);
-  std::vector<char> tmp((size_t)rows_ * colsBytes_);
-  download(tmp.data(), (size_t)colsBytes_);
-  other.upload(tmp.data(), (size_t)colsBytes_, rows_, colsBytes_);
+  YAK_CHECK(yakhip_copy_2d(context(), other.data_, other.step_, data_, step_, (size_t)colsBytes_, (size_t)rows_));  // :240
 }
 void DeviceMemory2D::upload(const void* host_ptr_arg, size_t host_step_arg, int rows_arg, int colsBytes_arg)
 {

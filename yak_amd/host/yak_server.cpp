@@ -79,6 +79,17 @@ yak::TSDFContainer FusionServer::downloadTSDF()
   return result;
 }
 
+bool FusionServer::uploadTSDF(const yak::TSDFContainer& volume)
+{
+  kfusion::cuda::TsdfVolume& vol = kinfu_->tsdf();
+  const kfusion::Vec3i dims = vol.getDims();
+  const auto have = volume.dims();
+  if (have.v[0] != dims[0] || have.v[1] != dims[1] || have.v[2] != dims[2])
+    return false;
+  vol.data().upload(volume.data(), volume.size64() * sizeof(std::uint32_t));  // same size: the buffer is kept
+  return true;
+}
+
 // yak_server.cpp:78-88
 bool FusionServer::step(const Eigen::Affine3f& current_pose, const Eigen::Affine3f& last_pose, const cv::Mat& depth)
 {
