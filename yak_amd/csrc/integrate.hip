@@ -912,7 +912,11 @@ int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in)
   p.tile_shift = choose_tile(ctx, p, vx);
   int chunk = 0;
   uint32_t nchunks = 0;
-  if ((rc = choose_chunk(ctx, p, blocks_x, 768u, 32, &chunk, &nchunks)) != 0)
+  // Layers of 4 MiB and more (the slabs of a 1024-wide volume) stream better in shorter walks: with no
+  // arithmetic at all an in-place sweep of 1024 x 1024 x 128 takes 201 us in 32-layer walks and 188 us in
+  // 16-layer walks (tools/rmw.hip; 512 x 512 x 512: 183 us); this kernel 0.203 -> 0.198 ms.
+  const int min_chunk = (uint64_t)p.plane * 4u >= (4ull << 20) ? 16 : 32;
+  if ((rc = choose_chunk(ctx, p, blocks_x, 768u, min_chunk, &chunk, &nchunks)) != 0)
     return rc;
   p.z_chunk = chunk;
 
