@@ -53,41 +53,58 @@ __device__ __forceinline__ float4 f4_at(const uint8_t* base, uint32_t pitch, int
   return ((const float4*)(base + (size_t)y * pitch))[x];
 }
 
+// Sum over the 64 lanes of a wave without touching LDS: six v_add_f32 with DPP operands (quad swaps, row
+// half mirror, row mirror, then the two row broadcasts of gfx9).  The total is valid in lane 63.  Measured
+// here, per launch: the __shfl_xor butterfly (ds_bpermute_b32, ~100 cycles each, 198 of them for the 33
+// values of a wave) took 2.2 us of a 9 us kernel.  The order of the additions is fixed, like the butterfly's.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_term(float v)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_lane63(float v)
+{
+  v += dpp_term<0xb1, 0xf>(v);   // quad_perm [1, 0, 3, 2]
+  v += dpp_term<0x4e, 0xf>(v);   // quad_perm [2, 3, 0, 1]
+  v += dpp_term<0x141, 0xf>(v);  // row_half_mirror: 8 lanes
+  v += dpp_term<0x140, 0xf>(v);  // row_mirror: 16 lanes
+  v += dpp_term<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3: 32 lanes
+  v += dpp_term<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3: lane 63 holds all 64
+  return v;
+}
+
 // Final reduction + solve + pose update of one linearisation, without leaving the device: the
 // reference goes back to the host after every one of its 19 linearisations per frame
 // (projective_icp.cpp:206-229: stream sync, cv::determinant, cv::solve, compose).
 //
 // reduce_partials: wave w of N_WAVES adds the workgroup partials of values w, w + N_WAVES, ... -- lane j
-// takes partials j, j + 64, ... in order, then the butterfly: the sum of a value does not depend on
+// takes partials j, j + 64, ... in order, then the wave sum: the sum of a value does not depend on
 // N_WAVES.  Results in LDS; the caller synchronises.
-template <int N_WAVES>
-__device__ __forceinline__ void reduce_partials(const float* partial, int n_blocks, float* sums)
+template <int N_WAVES, int DEEP>
+__device__ __forceinline__ void reduce_partials_deep(const float* partial, int n_blocks, float* sums)
 {
   const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-  // The partials were written by the previous launch's workgroups on every XCD, so each load here is a
-  // trip to the fabric (about a microsecond): a wave issues the loads of ALL its values, eight deep, before
-  // it adds anything -- one trip for up to 512 workgroups -- and then adds in the fixed order.
-  constexpr int kVals = (kValues + N_WAVES - 1) / N_WAVES, kDeep = 8;
+  constexpr int kVals = (kValues + N_WAVES - 1) / N_WAVES;
   float v[kVals];
 #pragma unroll
   for (int i = 0; i < kVals; ++i)
     v[i] = 0.f;
-  for (int b0 = lane; b0 < n_blocks; b0 += 64 * kDeep)
+  for (int b0 = lane; b0 < n_blocks; b0 += 64 * DEEP)
   {
-    float x[kVals][kDeep];
+    float x[kVals][DEEP];
 #pragma unroll
     for (int i = 0; i < kVals; ++i)
     {
       const int k = wave + i * N_WAVES;
 #pragma unroll
-      for (int u = 0; u < kDeep; ++u)
+      for (int u = 0; u < DEEP; ++u)
       {
-        const int b = b0 + 64 * u;
-        x[i][u] = k < kValues && b < n_blocks ? partial[(size_t)k * n_blocks + b] : 0.f;
+        const int b = b0 + 64 * u;  // 33 * n_blocks < 2^31 (the launchers bound the image size)
+        x[i][u] = k < kValues && b < n_blocks ? partial[(uint32_t)(k * n_blocks + b)] : 0.f;
       }
     }
 #pragma unroll
-    for (int u = 0; u < kDeep; ++u)
+    for (int u = 0; u < DEEP; ++u)
       if (b0 + 64 * u < n_blocks)
       {
 #pragma unroll
@@ -98,14 +115,27 @@ __device__ __forceinline__ void reduce_partials(const float* partial, int n_bloc
 #pragma unroll
   for (int i = 0; i < kVals; ++i)
   {
-    float r = v[i];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1)
-      r += __shfl_xor(r, off, 64);
+    const float r = wave_sum_lane63(v[i]);
     const int k = wave + i * N_WAVES;
-    if (lane == 0 && k < kValues)
+    if (lane == 63 && k < kValues)
       sums[k] = r;
   }
+}
+
+template <int N_WAVES>
+__device__ __forceinline__ void reduce_partials(const float* partial, int n_blocks, float* sums)
+{
+  // The partials were written by the previous launch's workgroups on every XCD, so each load here is a
+  // trip to the fabric (about a microsecond): a wave issues the loads of ALL its values before it adds
+  // anything -- one trip for up to 512 workgroups -- and then adds in the fixed order (which does not depend
+  // on the depth chosen here: lane j always takes partials j, j + 64, ...).  The coarse pyramid levels have
+  // few workgroups: they get a shallower body instead of dozens of loads that are predicated off.
+  if (n_blocks <= 64)  // wave-uniform
+    reduce_partials_deep<N_WAVES, 1>(partial, n_blocks, sums);
+  else if (n_blocks <= 128)
+    reduce_partials_deep<N_WAVES, 2>(partial, n_blocks, sums);
+  else
+    reduce_partials_deep<N_WAVES, 8>(partial, n_blocks, sums);
 }
 
 // 1 / sqrt(x) in double for normal positive x: the hardware estimate and two Newton steps (an ulp or two
@@ -399,19 +429,13 @@ __global__ __launch_bounds__(256) void icp_accumulate_kernel(const IcpParams p, 
     }
   }
 
-  // wave64 butterfly, then the four waves through LDS
+  // wave sums (in lane 63), then the four waves through LDS
 #pragma unroll
   for (int k = 0; k < kValues; ++k)
-  {
-    float v = acc[k];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1)
-      v += __shfl_xor(v, off, 64);
-    acc[k] = v;
-  }
+    acc[k] = wave_sum_lane63(acc[k]);
   __shared__ float lds[4][kValues];
   const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-  if (lane == 0)
+  if (lane == 63)
   {
 #pragma unroll
     for (int k = 0; k < kValues; ++k)
@@ -539,8 +563,9 @@ static int icp_scratch(yakhip_ctx* ctx, size_t need)
 // reads.  A single-workgroup launch finishes the last linearisation; the host waits once, at the end.
 // Measured per frame at 640 x 480, 10/5/4 linearisations: 0.34 ms with a reduce+solve launch behind every
 // accumulate launch (that launch alone took 13 us: five dependent trips to the fabric for the partials and
-// an IEEE-division Cholesky on one lane), 0.28 ms with this schedule; a launch now takes 11-13 us whatever
-// the level -- a chain of state + partials load, solve, gather, butterfly, store -- and the gaps 1-2 us.
+// an IEEE-division Cholesky on one lane), 0.28 ms with this schedule, 0.22 ms with DPP wave sums; a launch now
+// takes 9-10 us whatever the level -- a chain of state + partials load, solve, gather, sums, store -- and
+// the gaps 1-2 us.
 // (Folding the reduce+solve into the SAME accumulate launch -- last workgroup by ticket -- was measured and is
 // slower, 0.52 ms: the device-scope release/acquire fences every workgroup then needs write back and
 // invalidate the XCD's L2, which costs more than a launch.)
