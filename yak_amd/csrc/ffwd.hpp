@@ -118,6 +118,13 @@ YAK_FFWD_FN float yak_ffwd_accumulate(float x, float s, int n)
     // Xn * 2^(ex - 150): (float)Xn is exact, the scale is a normal power of two (ex >= 30)
     x = (float)Xn * yak_ffwd_float((uint32_t)(ex - 150 + 127) << 23);
     n -= k;
+    // the jump stops where the next sum would leave the binade (or n is used up): that step is a real
+    // addition anyway, so take it here instead of going round the loop for it
+    if (n > 0)
+    {
+      x = x + s;
+      --n;
+    }
   }
   return x;
 }

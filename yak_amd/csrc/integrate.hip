@@ -210,6 +210,7 @@ __device__ __forceinline__ void checkpoint_column(const IntegrateParams& p, floa
 
 // One launch per frame, two jobs (both read only the half ray-distance image):
 //   blocks [0, thr_blocks)   per-pixel {A2, B2}                       -> thr[rows][cols]
+//   (block numbers after the checkpoint workgroups, if any, which come first)
 //   blocks [thr_blocks, ..)  coarse[by][bx] = min A2 over the pixel window
 //                            [bk*bx, bk*bx + 2*bk) x [bk*by, bk*by + 2*bk) clipped to the image
 //                            (one wave per cell).  Any pixel box no larger than bk x bk whose low
@@ -217,18 +218,21 @@ __device__ __forceinline__ void checkpoint_column(const IntegrateParams& p, floa
 __global__ __launch_bounds__(256) void prepass_kernel(const uint8_t* dists, uint32_t dists_pitch, int rows, int cols,
                                                       float trunc_hi, f32x2* thr, float* coarse, int cw, int ch,
                                                       int bk, uint32_t thr_blocks_x, uint32_t thr_blocks,
-                                                      uint32_t ckpt_first_block, const IntegrateParams cp,
+                                                      uint32_t ckpt_blocks, const IntegrateParams cp,
                                                       float* ckpt_out)
 {
-  if (blockIdx.x >= ckpt_first_block)  // workgroups behind the image's: the column checkpoints of a deep slab
+  // the column checkpoints of a deep slab are the long job of this launch: its workgroups come first, the
+  // image's fill in behind them (ckpt_blocks = 0 for a slab that replays from layer 0)
+  if (blockIdx.x < ckpt_blocks)
   {
-    checkpoint_column(cp, ckpt_out, (blockIdx.x - ckpt_first_block) * 256u + threadIdx.x);
+    checkpoint_column(cp, ckpt_out, blockIdx.x * 256u + threadIdx.x);
     return;
   }
-  if (blockIdx.x < thr_blocks)
+  const uint32_t bid = blockIdx.x - ckpt_blocks;
+  if (bid < thr_blocks)
   {
-    const int x = (int)((blockIdx.x % thr_blocks_x) * 256u + threadIdx.x);
-    const int y = (int)(blockIdx.x / thr_blocks_x);
+    const int x = (int)((bid % thr_blocks_x) * 256u + threadIdx.x);
+    const int y = (int)(bid / thr_blocks_x);
     if (x >= cols)
       return;
     const uint32_t bits = *(const uint16_t*)(dists + (size_t)y * dists_pitch + (size_t)x * 2u);
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256) void prepass_kernel(const uint8_t* dists, uint
     thr[(size_t)y * cols + x] = ab;
     return;
   }
-  const int cell = (int)(blockIdx.x - thr_blocks) * 4 + (int)(threadIdx.x >> 6);
+  const int cell = (int)(bid - thr_blocks) * 4 + (int)(threadIdx.x >> 6);
   if (cell >= cw * ch)
     return;
   const int lane = (int)(threadIdx.x & 63u);
@@ -797,7 +801,7 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
     const uint32_t ckpt_blocks = p.ckpt ? (p.plane + 255u) / 256u : 0u;
     hipLaunchKernelGGL(prepass_kernel, dim3(thr_blocks + cell_blocks + ckpt_blocks), dim3(256), 0, ctx->stream, p.dists,
                        p.dists_pitch, p.rows, p.cols, p.trunc_hi, (f32x2*)base, (float*)(base + thr_bytes), p.cw, p.ch,
-                       bk, thr_blocks_x, thr_blocks, thr_blocks + cell_blocks, p, const_cast<float*>(p.ckpt));
+                       bk, thr_blocks_x, thr_blocks, ckpt_blocks, p, const_cast<float*>(p.ckpt));
     YAKHIP_TRY(hipGetLastError());
   }
 
