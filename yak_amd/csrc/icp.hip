@@ -6,8 +6,8 @@
 // The reference reduces each of the 27 products with its own 256-wide shared-memory tree and
 // __syncthreads pair (27 serial block reductions per 32 x 8 tile).  Here a lane walks several pixels
 // and keeps the 27 sums (+ 6 outcome counters, exact in fp32) in registers; a wave folds them with
-// cross-lane shuffles, the four waves of a workgroup meet once in LDS, and a second tiny kernel adds
-// the workgroup partials.  Every addition happens in a fixed order, so the result is deterministic
+// DPP adds (no LDS), the four waves of a workgroup meet once in LDS, and the workgroup partials are added by
+// a second tiny kernel -- or, in the device-resident loop, by the next linearisation's launch.  Every addition happens in a fixed order, so the result is deterministic
 // run to run (no float atomics).
 #include "yakhip_internal.h"
 
