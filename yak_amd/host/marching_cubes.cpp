@@ -7,7 +7,6 @@
 
 #include <algorithm>
 #include <cstring>
-#include <numeric>
 
 namespace yak
 {
@@ -52,21 +51,41 @@ PolygonMesh marchingCubesCPU(const TSDFContainer& tsdf, const MarchingCubesParam
     return mesh;
   }
 
-  // :204-216 -- exact point merging (bit patterns), then triangles with a repeated index are dropped
+  // :204-216 -- exact point merging (bit patterns), then triangles with a repeated index are dropped.
+  // Corners are sorted as packed 16-byte records {x, y, z bits, corner} (contiguous: a sort through an index
+  // array spends its time on cache misses); any strict order on the bit patterns groups equal points.
   const size_t corners = (size_t)n * 3;
-  std::vector<std::uint32_t> order(corners);
-  std::iota(order.begin(), order.end(), 0u);
-  auto key = [&tri](std::uint32_t c) { return &tri[(size_t)c * 3]; };
-  std::sort(order.begin(), order.end(), [&](std::uint32_t a, std::uint32_t b) {
-    return std::memcmp(key(a), key(b), 12) < 0;  // any strict order on bit patterns groups equal points
-  });
-  std::vector<std::uint32_t> index(corners);
+  struct Corner
+  {
+    std::uint32_t x, y, z, c;
+  };
+  std::vector<Corner> order(corners);
   for (size_t i = 0; i < corners; ++i)
   {
-    if (i == 0 || std::memcmp(key(order[i]), key(order[i - 1]), 12) != 0)
-      mesh.cloud.push_back({ key(order[i])[0], key(order[i])[1], key(order[i])[2] });
-    index[order[i]] = (std::uint32_t)(mesh.cloud.size() - 1);
+    std::memcpy(&order[i], &tri[i * 3], 12);
+    order[i].c = (std::uint32_t)i;
   }
+  std::sort(order.begin(), order.end(), [](const Corner& a, const Corner& b) {
+    if (a.x != b.x)
+      return a.x < b.x;
+    if (a.y != b.y)
+      return a.y < b.y;
+    if (a.z != b.z)
+      return a.z < b.z;
+    return a.c < b.c;
+  });
+  std::vector<std::uint32_t> index(corners);
+  mesh.cloud.reserve(corners / 5);
+  for (size_t i = 0; i < corners; ++i)
+  {
+    if (i == 0 || order[i].x != order[i - 1].x || order[i].y != order[i - 1].y || order[i].z != order[i - 1].z)
+    {
+      const float* p = &tri[(size_t)order[i].c * 3];
+      mesh.cloud.push_back({ p[0], p[1], p[2] });
+    }
+    index[order[i].c] = (std::uint32_t)(mesh.cloud.size() - 1);
+  }
+  mesh.polygons.reserve((size_t)n);
   for (size_t i = 0; i < (size_t)n; ++i)
   {
     const std::uint32_t a = index[3 * i], b = index[3 * i + 1], c = index[3 * i + 2];
