@@ -8,11 +8,60 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
 #include <memory>
+#include <new>
 #include <vector>
 
 namespace yak
 {
+class FusionServer;
+
+namespace detail
+{
+// std::allocator, except that (a) value-less construction leaves the element alone, so vector(n) does not
+// touch its memory, and (b) large blocks are 2 MiB aligned (the .cpp asks the kernel for huge pages on them).
+// FusionServer::downloadTSDF fills a container it is about to overwrite anyway: without this the 512 MiB of
+// a 512^3 volume are written twice and faulted in 4 KiB at a time (120 ms against 19 ms for the copy itself).
+template <typename T>
+struct LazyAllocator
+{
+  typedef T value_type;
+  LazyAllocator() {}
+  template <typename U>
+  LazyAllocator(const LazyAllocator<U>&)
+  {
+  }
+  T* allocate(std::size_t n);
+  void deallocate(T* p, std::size_t) { std::free(p); }
+  template <typename U>
+  void construct(U*)
+  {
+  }
+  template <typename U, typename A, typename... Rest>
+  void construct(U* p, A&& a, Rest&&... rest)
+  {
+    ::new ((void*)p) U(static_cast<A&&>(a), static_cast<Rest&&>(rest)...);
+  }
+  template <typename U>
+  bool operator==(const LazyAllocator<U>&) const
+  {
+    return true;
+  }
+  template <typename U>
+  bool operator!=(const LazyAllocator<U>&) const
+  {
+    return false;
+  }
+};
+void* lazy_allocate(std::size_t bytes);  // tsdf_container.cpp
+template <typename T>
+T* LazyAllocator<T>::allocate(std::size_t n)
+{
+  return static_cast<T*>(lazy_allocate(n * sizeof(T)));
+}
+}  // namespace detail
+
 struct Vector3i
 {
   int v[3];
@@ -56,12 +105,18 @@ public:
   Vector3i dims() const { return dims_; }
 
 private:
+  friend class FusionServer;
+  struct Uninitialized
+  {
+  };
+  /** Contents unspecified: for a container that is overwritten at once (FusionServer::downloadTSDF). */
+  TSDFContainer(int x, int y, int z, Uninitialized);
   static void unpack(std::uint32_t word, std::uint16_t& dist, std::uint16_t& weight)
   {
     std::memcpy(&dist, &word, 2);
     std::memcpy(&weight, ((const char*)(&word)) + 2, 2);
   }
-  std::shared_ptr<std::vector<std::uint32_t>> data_;
+  std::shared_ptr<std::vector<std::uint32_t, detail::LazyAllocator<std::uint32_t>>> data_;
   Vector3i dims_;
 };
 }  // namespace yak

@@ -3,11 +3,46 @@
 #include <yak/yak_server.h>
 
 #include <cstdlib>
+#if defined(__linux__)
+#include <sys/mman.h>
+#endif
 
 namespace yak
 {
+namespace detail
+{
+void* lazy_allocate(std::size_t bytes)
+{
+  const std::size_t huge = (std::size_t)2 << 20;
+  void* p = nullptr;
+  if (bytes >= 16 * huge)
+  {
+    if (posix_memalign(&p, huge, (bytes + huge - 1) / huge * huge) != 0)
+      p = nullptr;
+#if defined(__linux__) && defined(MADV_HUGEPAGE)
+    if (p)
+      madvise(p, bytes, MADV_HUGEPAGE);  // advice only: a refusal changes nothing but speed
+#endif
+  }
+  else
+    p = std::malloc(bytes ? bytes : 1);
+  if (!p)
+    throw std::bad_alloc();
+  return p;
+}
+}  // namespace detail
+
+typedef std::vector<std::uint32_t, detail::LazyAllocator<std::uint32_t>> VoxelVector;
+
 TSDFContainer::TSDFContainer(int x, int y, int z)
-  : data_(std::make_shared<std::vector<std::uint32_t>>((std::size_t)x * (std::size_t)y * (std::size_t)z, 0u))
+  : data_(std::make_shared<VoxelVector>((std::size_t)x * (std::size_t)y * (std::size_t)z, 0u))
+{
+  dims_.v[0] = x;
+  dims_.v[1] = y;
+  dims_.v[2] = z;
+}
+TSDFContainer::TSDFContainer(int x, int y, int z, Uninitialized)
+  : data_(std::make_shared<VoxelVector>((std::size_t)x * (std::size_t)y * (std::size_t)z))
 {
   dims_.v[0] = x;
   dims_.v[1] = y;
@@ -74,7 +109,7 @@ yak::TSDFContainer FusionServer::downloadTSDF()
 {
   const kfusion::cuda::TsdfVolume& vol = kinfu_->tsdf();
   const kfusion::Vec3i dims = vol.getDims();
-  yak::TSDFContainer result(dims[0], dims[1], dims[2]);
+  yak::TSDFContainer result(dims[0], dims[1], dims[2], yak::TSDFContainer::Uninitialized());  // overwritten below
   vol.data().download(result.data());
   return result;
 }
