@@ -28,6 +28,15 @@ def test_phong_known_pixels():
     assert (img[..., 0] == img[..., 1]).all() and (img[..., 1] == img[..., 2]).all() and (img[..., 3] == 0).all()
 
 
+def test_a_nan_normal_under_a_valid_point_keeps_the_ambient_term():
+    # fmax(0, NaN) = 0 in both Phong terms (imgproc.cu:494): what is left is the ambient 0.3 -> 76
+    img = oracle.render_image(*maps([(0, 0, 1), (0.1, 0, 2)], [(np.nan, np.nan, np.nan), (0, np.nan, -1)]), light_pose=(0, 0, 0))
+    assert img[0, 0].tolist() == [76, 76, 76, 0] and img[0, 1].tolist() == [76, 76, 76, 0]
+    # a point ON the light (L = 0 / 0) likewise
+    img = oracle.render_image(*maps([(0.5, 0.5, 1)], [(0, 0, -1)]), light_pose=(0.5, 0.5, 1))
+    assert img[0, 0].tolist() == [76, 76, 76, 0]
+
+
 def test_backdrop_where_there_is_no_point():
     rows, cols = 480, 3
     p = np.full((rows, cols, 4), np.nan, dtype=np.float32)

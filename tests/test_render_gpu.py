@@ -83,6 +83,31 @@ def test_tangent_colours_and_side_by_side_layout(gpu_ctx):
     assert want[5, 7].tolist() == [0, 255, 0, 0] and want[6, 7].tolist() == [255, 0, 255, 0]
 
 
+def test_render_degenerate_pixels(gpu_ctx):
+    """NaN normals under valid points, a point on the light, a point at the eye, zero-length normals."""
+    pts = np.zeros((4, 64, 4), dtype=np.float32)
+    nrm = np.zeros_like(pts)
+    pts[..., 2] = 1.0
+    pts[0, :, 0] = np.linspace(-1, 1, 64)
+    nrm[..., 2] = -1.0
+    nrm[1, :, :3] = np.nan                      # both Phong terms drop out (fmax(0, NaN) = 0): ambient only
+    pts[2, 5, :3] = (0.5, -0.3, -1.0)           # on the light
+    pts[2, 6, :3] = 0.0                         # at the eye
+    nrm[3, :, :3] = 0.0                         # zero normal: R = -L
+    pts[3, 7, 0] = np.nan                       # backdrop
+    dp, dn = dev_f4(pts), dev_f4(nrm)
+    img = torch.zeros((4, 64), dtype=torch.int32, device="cuda")
+    gpu_ctx.render_image_points(dp.data_ptr(), 64 * 16, dn.data_ptr(), 64 * 16, 4, 64, LIGHTS[1], img.data_ptr(), 64 * 4)
+    tan = torch.zeros((4, 64), dtype=torch.int32, device="cuda")
+    gpu_ctx.render_tangent_colors(dn.data_ptr(), 64 * 16, 4, 64, tan.data_ptr(), 64 * 4)
+    torch.cuda.synchronize()
+    got = img.cpu().numpy().view(np.uint8).reshape(4, 64, 4)
+    want = oracle.render_image(pts, nrm, LIGHTS[1])
+    assert np.array_equal(got, want)
+    assert (want[1, :, :3] == 76).all() and want[2, 5].tolist() == [76, 76, 76, 0]
+    assert np.array_equal(tan.cpu().numpy().view(np.uint8).reshape(4, 64, 4), oracle.render_tangent_colors(nrm))
+
+
 def test_render_rejects_bad_arguments(gpu_ctx):
     from yak_amd.capi import YakHipError
     buf = torch.zeros((8, 8, 4), dtype=torch.float32, device="cuda")
