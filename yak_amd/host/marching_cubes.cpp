@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <thread>
 
 namespace yak
 {
@@ -65,7 +66,7 @@ PolygonMesh marchingCubesCPU(const TSDFContainer& tsdf, const MarchingCubesParam
     std::memcpy(&order[i], &tri[i * 3], 12);
     order[i].c = (std::uint32_t)i;
   }
-  std::sort(order.begin(), order.end(), [](const Corner& a, const Corner& b) {
+  const auto less = [](const Corner& a, const Corner& b) {
     if (a.x != b.x)
       return a.x < b.x;
     if (a.y != b.y)
@@ -73,7 +74,26 @@ PolygonMesh marchingCubesCPU(const TSDFContainer& tsdf, const MarchingCubesParam
     if (a.z != b.z)
       return a.z < b.z;
     return a.c < b.c;
-  });
+  };
+  // four sorted quarters on four threads, merged pairwise: the sort is most of this routine's time
+  const size_t parts = corners >= (1u << 16) ? 4 : 1;
+  if (parts == 1)
+    std::sort(order.begin(), order.end(), less);
+  else
+  {
+    size_t cut[5];
+    for (size_t k = 0; k <= 4; ++k)
+      cut[k] = corners * k / 4;
+    std::vector<std::thread> pool;
+    for (size_t k = 0; k < 4; ++k)
+      pool.emplace_back([&, k] { std::sort(order.begin() + cut[k], order.begin() + cut[k + 1], less); });
+    for (auto& t : pool)
+      t.join();
+    std::thread left([&] { std::inplace_merge(order.begin(), order.begin() + cut[1], order.begin() + cut[2], less); });
+    std::inplace_merge(order.begin() + cut[2], order.begin() + cut[3], order.end(), less);
+    left.join();
+    std::inplace_merge(order.begin(), order.begin() + cut[2], order.end(), less);
+  }
   std::vector<std::uint32_t> index(corners);
   mesh.cloud.reserve(corners / 5);
   for (size_t i = 0; i < corners; ++i)
