@@ -78,6 +78,7 @@ struct IntegrateParams
   int X, Y;              // in-plane extent
   int z0, z1;            // owned layers
   int z_chunk;           // layers walked by one workgroup (grid.y index)
+  int chunk_alt;         // 1: chunks are handed out shallow and deep in turn (integrate.hip chunk_of_block)
   int tile_shift;        // log2 of the lanes a wave lays along x (6 = layer order); integrate.hip lane_voxels()
   uint32_t plane;        // X * Y
   float vsx, vsy, vsz;
