@@ -174,12 +174,18 @@ def kinfu_loop_row(ctx):
     at 512^3 on the S2 orbit, tracking from depth alone; and with supplied poses."""
     from yak_amd.loop import run_kinfu_loop
 
-    run_kinfu_loop(ctx, VOXELS_PER_RANK_EDGE, 8, "device")  # warm-up: allocations, first launches
-    # wall-clock rates of a 50 ms run: the better of two runs each (the host side is Python and the box is shared)
+    from yak_amd import synth
+
+    frames = 300  # BASELINE.json configs[2]: the whole orbit
+    scene = [synth.scene_s2(f, noise_mm=1.0) for f in range(frames)]
+    run_kinfu_loop(ctx, VOXELS_PER_RANK_EDGE, 8, "device", scene)  # warm-up: allocations, first launches
+    # wall-clock rates of a 0.25 s run: the better of two runs each (the host side is Python and the box is shared)
     best = lambda a, b: a if a["frames_per_s"] >= b["frames_per_s"] else b  # noqa: E731
-    r = best(run_kinfu_loop(ctx, VOXELS_PER_RANK_EDGE, 60, "device"), run_kinfu_loop(ctx, VOXELS_PER_RANK_EDGE, 60, "device"))
-    p = best(run_kinfu_loop(ctx, VOXELS_PER_RANK_EDGE, 60, None), run_kinfu_loop(ctx, VOXELS_PER_RANK_EDGE, 60, None))
-    return {"workload": "512^3, 60 frames of the S2 orbit (1.2 deg per frame, 1 mm depth noise), depth frames resident in HBM; "
+    r = best(run_kinfu_loop(ctx, VOXELS_PER_RANK_EDGE, frames, "device", scene),
+             run_kinfu_loop(ctx, VOXELS_PER_RANK_EDGE, frames, "device", scene))
+    p = best(run_kinfu_loop(ctx, VOXELS_PER_RANK_EDGE, frames, None, scene),
+             run_kinfu_loop(ctx, VOXELS_PER_RANK_EDGE, frames, None, scene))
+    return {"workload": "512^3, the 300 frames of the S2 orbit (1.2 deg per frame, 1 mm depth noise), depth frames resident in HBM; "
                         "per frame: compute_dists, bilateral, 3-level pyramid, point/normal maps, ICP 10/5/4 linearisations "
                         "(device-resident loop), integrate, raycast, 2x2 resize; host waits once per frame",
             "fused_frames_per_s": round(r["frames_per_s"], 1),

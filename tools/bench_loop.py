@@ -27,6 +27,12 @@ def main():
         r["n"], r["frames"], {None: "off (true poses)", "host": "on (host loop)", "device": "on (device loop)"}[mode],
         r["frames_per_s"], r["wall_s"], r["worst_position_error_mm"]))
     print("per frame, stream time between events [ms]: " + ", ".join("%s %.3f" % kv for kv in r["stage_ms"].items()))
+    ms = r["icp_ms_per_frame"][1:]
+    if mode == "device" and ms:
+        med = sorted(ms)[len(ms) // 2]
+        slow = [i + 1 for i, v in enumerate(ms) if v > 2.0 * med]
+        print("ICP per frame: median %.3f ms, max %.3f ms; %d frames above twice the median (host-solve path): %s" % (
+            med, max(ms), len(slow), slow[:40]))
     ctx.close()
 
 

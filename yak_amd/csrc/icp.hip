@@ -211,7 +211,32 @@ __device__ __forceinline__ void solve_update(const float* sums, IcpState& st)
     }
   }
   const double m = trace * 0.2;
-  const bool certified = spd && det > 1e-12 && det > 2.0 * 1.1920928955078125e-7 * trace * (m * m * m * m * m) * 4.0;
+  const double cutoff = 2.0 * 1.1920928955078125e-7 * trace * 4.0;  // OpenCV's singular-value cut-off, with a margin of 4
+  bool certified = spd && det > 1e-12 && det > cutoff * (m * m * m * m * m);
+  if (!certified && spd && det > 1e-12)
+  {
+    // The AM-GM bound is loose when the eigenvalues are spread (views where one direction is weakly
+    // constrained: 11 frames of the 300-frame orbit).  Rare path, the tight bound: lambda_min >= 1 / trace(A^-1)
+    // = 1 / ||L^-1||_F^2 (within a factor of 6 of lambda_min), from the triangular inverse of the factor at hand.
+    double M[6][6], frob = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+    {
+      M[j][j] = inv[j];
+      frob += inv[j] * inv[j];
+#pragma unroll
+      for (int i = j + 1; i < 6; ++i)
+      {
+        double v = 0.0;
+#pragma unroll
+        for (int k = j; k < i; ++k)
+          v -= A[i][k] * M[k][j];
+        M[i][j] = v * inv[i];
+        frob += M[i][j] * M[i][j];
+      }
+    }
+    certified = frob * cutoff < 1.0;
+  }
   if (!certified)
   {
     st.status = 2;

@@ -19,9 +19,10 @@ def rodrigues(r):
     return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * K @ K
 
 
-def run_kinfu_loop(ctx, n=512, frames=60, icp="device"):
+def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None):
     """icp: "device" (yakhip_icp_estimate, one wait per frame), "host" (one blocking linearisation at a time,
-    numpy solve) or None (true poses supplied).  Returns a dict with frames/s and per-stage stream times."""
+    numpy solve) or None (true poses supplied).  scene: the frames, if the caller made them already (a list of
+    synth.scene_s2(f, noise_mm=1.0) for f in range(frames)).  Returns a dict with frames/s and per-stage stream times."""
     import torch
 
     from . import capi, synth
@@ -42,8 +43,10 @@ def run_kinfu_loop(ctx, n=512, frames=60, icp="device"):
     prv_n = [f4(rows >> l, cols >> l) for l in range(LEVELS)]
 
     n_frames = int(frames)
-    scene = [synth.scene_s2(f, noise_mm=1.0) for f in range(n_frames)]
-    dev_depth = [torch.from_numpy(d.view(np.int16)).cuda() for d, _, _ in scene]
+    if scene is None:
+        scene = [synth.scene_s2(f, noise_mm=1.0) for f in range(n_frames)]
+    assert len(scene) >= n_frames
+    dev_depth = [torch.from_numpy(d.view(np.int16)).cuda() for d, _, _ in scene[:n_frames]]
     # poses are camera -> volume; frame 0 is integrated at its true pose
     def c2v(R_v2c, t_v2c):
         R = R_v2c.astype(np.float64).T
@@ -55,6 +58,7 @@ def run_kinfu_loop(ctx, n=512, frames=60, icp="device"):
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     worst = 0.0
+    icp_ms = []
     for f in range(n_frames):
         e = [ev() for _ in range(5)]
         e[0].record()
@@ -114,8 +118,10 @@ def run_kinfu_loop(ctx, n=512, frames=60, icp="device"):
         torch.cuda.synchronize()
         for name, a, b_ in (("preprocess", 0, 1), ("icp", 1, 2), ("integrate", 2, 3), ("raycast", 3, 4)):
             stage[name] += e[a].elapsed_time(e[b_])
+        icp_ms.append(e[1].elapsed_time(e[2]))
         tR, tt = c2v(scene[f][1], scene[f][2])
         worst = max(worst, float(np.linalg.norm(pose_t - tt)))
     wall = time.perf_counter() - t_start
     return {"n": n, "frames": n_frames, "icp": icp, "frames_per_s": n_frames / wall, "wall_s": wall,
-            "worst_position_error_mm": worst * 1e3, "stage_ms": {k: v / n_frames for k, v in stage.items()}}
+            "worst_position_error_mm": worst * 1e3, "stage_ms": {k: v / n_frames for k, v in stage.items()},
+            "icp_ms_per_frame": icp_ms}
