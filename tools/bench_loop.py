@@ -31,8 +31,8 @@ def main():
     if mode == "device" and ms:
         med = sorted(ms)[len(ms) // 2]
         slow = [i + 1 for i, v in enumerate(ms) if v > 2.0 * med]
-        print("ICP per frame: median %.3f ms, max %.3f ms; %d frames above twice the median (host-solve path): %s" % (
-            med, max(ms), len(slow), slow[:40]))
+        print("ICP per frame: median %.3f ms, max %.3f ms; %d frames above twice the median (first call, host-solve path or a host stall): %s" % (
+            med, max(ms), len(slow), ["%d: %.2f ms" % (i, ms[i - 1]) for i in slow[:40]]))
     ctx.close()
 
 

@@ -19,7 +19,7 @@ def rodrigues(r):
     return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * K @ K
 
 
-def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None):
+def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None, on_system=None):
     """icp: "device" (yakhip_icp_estimate, one wait per frame), "host" (one blocking linearisation at a time,
     numpy solve) or None (true poses supplied).  scene: the frames, if the caller made them already (a list of
     synth.scene_s2(f, noise_mm=1.0) for f in range(frames)).  Returns a dict with frames/s and per-stage stream times."""
@@ -55,6 +55,12 @@ def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None):
 
     stage = {k: 0.0 for k in ("preprocess", "icp", "integrate", "raycast")}
     ev = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
+    # the collector's pauses land between two launches and show up as stream time (a 33 ms full collection at
+    # frame 237 of the orbit, 1 ms ones elsewhere): none inside the timed loop
+    import gc
+    gc.collect()
+    gc_was_enabled = gc.isenabled()
+    gc.disable()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     worst = 0.0
@@ -91,6 +97,8 @@ def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None):
                                 else:
                                     A[i, j] = A[j, i] = sums[k]
                                 k += 1
+                        if on_system is not None:  # diagnostics: on_system(frame, level, A, b)
+                            on_system(f, l, A, b)
                         x = np.linalg.solve(A, b)
                         Ri = rodrigues(x[:3])
                         R, t = Ri @ R, Ri @ t + x[3:]
@@ -122,6 +130,8 @@ def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None):
         tR, tt = c2v(scene[f][1], scene[f][2])
         worst = max(worst, float(np.linalg.norm(pose_t - tt)))
     wall = time.perf_counter() - t_start
+    if gc_was_enabled:
+        gc.enable()
     return {"n": n, "frames": n_frames, "icp": icp, "frames_per_s": n_frames / wall, "wall_s": wall,
             "worst_position_error_mm": worst * 1e3, "stage_ms": {k: v / n_frames for k, v in stage.items()},
             "icp_ms_per_frame": icp_ms}
