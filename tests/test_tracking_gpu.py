@@ -325,6 +325,43 @@ def test_icp_estimate_device_loop_equals_host_loop(gpu_ctx):
     assert Rd2 == Rd and td2 == td
 
 
+def test_icp_estimate_weakly_constrained_view_stays_on_the_device(gpu_ctx):
+    """Frames 250-260 of the orbit: the eigenvalues of the normal matrix are spread so far that the device
+    solve's first certificate (AM-GM bound on lambda_min, icp.hip solve_update) fails although lambda_min is
+    two orders of magnitude above OpenCV's cut-off; the second one (1 / trace(A^-1)) certifies the Cholesky
+    solve.  Either way the pose must equal the host loop's."""
+    prev = [level_maps(254, l) for l in range(3)]
+    curr = [level_maps(256, l) for l in range(3)]
+    dev = [[dev_f4(a) for a in (curr[l][0], curr[l][1], prev[l][0], prev[l][1])] for l in range(3)]
+    shapes = [curr[l][0].shape[:2] for l in range(3)]
+    # the case is what it claims to be (first linearisation of the coarsest level, GPU sums)
+    args = []
+    for b in dev[2]:
+        args += [b.data_ptr(), b.stride(0) * 4]
+    sums, _ = gpu_ctx.icp_accumulate(np.eye(3, dtype=np.float32).reshape(-1), np.zeros(3, dtype=np.float32), synth.INTR, 2,
+                                     0.1, math.radians(30.0), *args, *shapes[2])
+    A, k = np.zeros((6, 6)), 0
+    for i in range(6):
+        for j in range(i, 7):
+            if j < 6:
+                A[i, j] = A[j, i] = sums[k]
+            k += 1
+    w = np.linalg.eigvalsh(A)
+    cut = 4.0 * 2.0 * 1.1920928955078125e-7 * np.trace(A)
+    assert np.prod(w) / (np.trace(A) / 5.0) ** 5 < cut          # AM-GM bound: not certified
+    assert 1.0 / np.sum(1.0 / w) > 10.0 * cut                   # tight bound: certified with room
+    levels = [(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[0].stride(0) * 4, shapes[l][0],
+               shapes[l][1], it) for l, (d, it) in enumerate(zip(dev, (4, 5, 10)))]
+    Rd, td, ok = gpu_ctx.icp_estimate(np.eye(3).reshape(-1), np.zeros(3), synth.INTR, 0.1, math.radians(30.0), levels)
+    Rh, th, okh = _gn_loop_python(gpu_ctx, dev, shapes, ((2, 10), (1, 5), (0, 4)), np.eye(3), np.zeros(3))
+    assert ok and okh
+    assert np.abs(np.array(Rd).reshape(3, 3) - Rh).max() < 1e-5 and np.abs(np.array(td) - th).max() < 1e-5
+    Rp, tp, Rc, tc = prev[0][2], prev[0][3], curr[0][2], curr[0][3]
+    R_true = Rp @ Rc.T
+    t_true = tp - R_true @ tc
+    assert np.abs(np.array(Rd).reshape(3, 3) - R_true).max() < 2e-3 and np.linalg.norm(np.array(td) - t_true) < 5e-3
+
+
 def test_icp_estimate_degenerate_inputs_take_the_host_path(gpu_ctx):
     # no data at all: the normal matrix is zero, the reference's determinant test fails the frame
     p, n, _, _ = level_maps(10, 2)
