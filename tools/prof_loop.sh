@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_loop
 rm -rf $O && mkdir -p $O
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/tools/bench_loop.py > $O/bench_loop.txt 2> $O/trace.log || exit 1
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/tools/bench_loop.py --frames 300 > $O/bench_loop.txt 2> $O/trace.log || exit 1
 cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 python3 - $O/kernel_stats.csv <<'PY'
 import csv, sys

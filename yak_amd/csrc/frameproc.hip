@@ -18,30 +18,65 @@ __device__ __forceinline__ int u16_at(const uint8_t* base, uint32_t pitch, int y
   return ((const unsigned short*)(base + (size_t)y * pitch))[x];
 }
 
-// imgproc.cu:10-42
+// imgproc.cu:10-42.  KSZ > 0: the kernel size is known at compile time, and a workgroup whose 64 x 4 tile and
+// window lie inside the image takes the taps of a window as one batch of loads (the general loop has per-lane
+// bounds, so every tap waits for its own load: 49 trips to the L1 in a row, 20 us a frame) and then the same
+// statements in the same order.  KSZ == 0: any size, the loop as written.
+__device__ __forceinline__ void bilateral_tap(int value, int depth, int dx, int dy, float sigma_spatial2_inv_half,
+                                              float sigma_depth2_inv_half, float& sum1, float& sum2)
+{
+  const float space2 = (float)(dx * dx + dy * dy);
+  const int dd = value - depth;
+  const float color2 = (float)(int)((unsigned)dd * (unsigned)dd);  // int product, wraps as the source's does
+  const float weight = expf(-(space2 * sigma_spatial2_inv_half + color2 * sigma_depth2_inv_half));
+  sum1 += (float)depth * weight;
+  sum2 += weight;
+}
+
+template <int KSZ>
 __global__ __launch_bounds__(256) void bilateral_kernel(const uint8_t* src, uint32_t src_pitch, uint8_t* dst,
                                                         uint32_t dst_pitch, int rows, int cols, int ksz,
                                                         float sigma_spatial2_inv_half, float sigma_depth2_inv_half)
 {
   const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
   const int y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
-  if (x >= cols || y >= rows)
-    return;
-  const int value = u16_at(src, src_pitch, y, x);
-  const int tx = min(x - ksz / 2 + ksz, cols - 1);
-  const int ty = min(y - ksz / 2 + ksz, rows - 1);
   float sum1 = 0.f, sum2 = 0.f;
-  for (int cy = max(y - ksz / 2, 0); cy < ty; ++cy)
-    for (int cx = max(x - ksz / 2, 0); cx < tx; ++cx)
+  bool done = false;
+  if constexpr (KSZ > 0)
+  {
+    const int bx0 = (int)(blockIdx.x * 64u), by0 = (int)(blockIdx.y * 4u);
+    // every pixel of the tile: max(. - KSZ / 2, 0) and min(. - KSZ / 2 + KSZ, size - 1) do not clip
+    if (bx0 - KSZ / 2 >= 0 && bx0 + 63 - KSZ / 2 + KSZ <= cols - 1 && by0 - KSZ / 2 >= 0 &&
+        by0 + 3 - KSZ / 2 + KSZ <= rows - 1)  // workgroup-uniform
     {
-      const int depth = u16_at(src, src_pitch, cy, cx);
-      const float space2 = (float)((x - cx) * (x - cx) + (y - cy) * (y - cy));
-      const int dd = value - depth;
-      const float color2 = (float)(int)((unsigned)dd * (unsigned)dd);  // int product, wraps as the source's does
-      const float weight = expf(-(space2 * sigma_spatial2_inv_half + color2 * sigma_depth2_inv_half));
-      sum1 += (float)depth * weight;
-      sum2 += weight;
+      const int value = u16_at(src, src_pitch, y, x);
+      int d[KSZ][KSZ];
+#pragma unroll
+      for (int j = 0; j < KSZ; ++j)
+#pragma unroll
+        for (int i = 0; i < KSZ; ++i)
+          d[j][i] = u16_at(src, src_pitch, y - KSZ / 2 + j, x - KSZ / 2 + i);
+#pragma unroll
+      for (int j = 0; j < KSZ; ++j)
+#pragma unroll
+        for (int i = 0; i < KSZ; ++i)
+          bilateral_tap(value, d[j][i], KSZ / 2 - i, KSZ / 2 - j, sigma_spatial2_inv_half, sigma_depth2_inv_half, sum1,
+                        sum2);
+      done = true;
     }
+  }
+  if (!done)
+  {
+    if (x >= cols || y >= rows)
+      return;
+    const int value = u16_at(src, src_pitch, y, x);
+    const int tx = min(x - ksz / 2 + ksz, cols - 1);
+    const int ty = min(y - ksz / 2 + ksz, rows - 1);
+    for (int cy = max(y - ksz / 2, 0); cy < ty; ++cy)
+      for (int cx = max(x - ksz / 2, 0); cx < tx; ++cx)
+        bilateral_tap(value, u16_at(src, src_pitch, cy, cx), x - cx, y - cy, sigma_spatial2_inv_half,
+                      sigma_depth2_inv_half, sum1, sum2);
+  }
   const float q = sum1 / sum2;
   // __float2int_rn: round half even; NaN (an all-underflow window) -> 0
   const int r = q != q ? 0 : (int)__builtin_rintf(q);
@@ -273,9 +308,13 @@ int launch_bilateral(const yakhip_ctx* ctx, const uint8_t* src, size_t src_pitch
                      int rows, int cols, int kernel_size, float sigma_spatial, float sigma_depth)
 {
   sigma_depth *= 1000;  // imgproc.cu:48 metres -> mm
-  hipLaunchKernelGGL(bilateral_kernel, image_grid(rows, cols), dim3(256), 0, ctx->stream, src, (uint32_t)src_pitch, dst,
-                     (uint32_t)dst_pitch, rows, cols, kernel_size, 0.5f / (sigma_spatial * sigma_spatial),
-                     0.5f / (sigma_depth * sigma_depth));  // :54
+  const float ss = 0.5f / (sigma_spatial * sigma_spatial), sd = 0.5f / (sigma_depth * sigma_depth);  // :54
+  if (kernel_size == 7)  // the size KinFu uses (kinfu.cpp:28)
+    hipLaunchKernelGGL(bilateral_kernel<7>, image_grid(rows, cols), dim3(256), 0, ctx->stream, src, (uint32_t)src_pitch,
+                       dst, (uint32_t)dst_pitch, rows, cols, kernel_size, ss, sd);
+  else
+    hipLaunchKernelGGL(bilateral_kernel<0>, image_grid(rows, cols), dim3(256), 0, ctx->stream, src, (uint32_t)src_pitch,
+                       dst, (uint32_t)dst_pitch, rows, cols, kernel_size, ss, sd);
   return check(hipGetLastError(), "bilateral_kernel launch");
 }
 
