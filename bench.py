@@ -59,7 +59,7 @@ def cpu_baseline(dims, vs, tr, dists, R, t, intr, max_weight):
     _, upd1 = oracle.integrate(slab, dims, vs, tr, max_weight, dists, R, t, intr, z0=0, z1=layers, nthreads=1)
     t1 = time.perf_counter() - t0
     reps, upd, tm = 0, 0, 0.0
-    while tm < 6.0 and reps < 200:  # about 6 s of all-core work (plus the one-thread pass above)
+    while tm < 10.0 and reps < 2000:  # about 10 s of all-core work (plus the one-thread pass above)
         slab[:] = 0
         t0 = time.perf_counter()
         _, u = oracle.integrate(slab, dims, vs, tr, max_weight, dists, R, t, intr, z0=0, z1=layers, nthreads=threads)
