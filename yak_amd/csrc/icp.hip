@@ -154,7 +154,8 @@ __device__ __forceinline__ double fast_rsqrt(double x)
 // The normal matrix is symmetric positive definite whenever the reference's own checks pass, so a
 // Cholesky factorisation in double gives the solution cv::solve's SVD gives, as long as the SVD would
 // not truncate a singular value.  That is certified, not assumed: lambda_min >= det / (trace / 5)^5
-// (AM-GM on the other five eigenvalues) must exceed OpenCV's cut-off 2 * FLT_EPSILON * trace, and det
+// (AM-GM on the other five eigenvalues) or, failing that, lambda_min >= 1 / trace(A^-1) (the triangular
+// inverse of the factor, rare path) must exceed OpenCV's cut-off 2 * FLT_EPSILON * trace four times, and det
 // must be clear of the 1e-15 test; anything else sets status = 2 and the host's LU / SVD path
 // (solve6.hpp) redoes the estimate.
 __device__ __forceinline__ void solve_update(const float* sums, IcpState& st)
