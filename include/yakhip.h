@@ -324,6 +324,17 @@ int yakhip_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], con
 int yakhip_marching_cubes(yakhip_ctx* ctx, const yakhip_volume* vol, int min_weight, double scale, void* triangles_dev,
                           unsigned long long capacity_triangles, unsigned long long* n_triangles_host);
 
+/* The exact part of MarchingCubesParameters::clean (yak/src/mc/marching_cubes.cpp:204-216: vtkCleanPolyData,
+ * point merging on): corners of the triangle soup with the same three bit patterns become one vertex.
+ * triangles_dev: n_triangles * 9 floats as yakhip_marching_cubes writes them.  vertices_dev (3 floats per
+ * vertex, room for 3 * n_triangles of them) receives the distinct points in ascending order of their
+ * (x, y, z) bit patterns read as unsigned integers; index_dev (one uint32 per corner, 3 * n_triangles)
+ * receives each corner's vertex.  Dropping triangles that repeat an index is left to the caller (one linear
+ * pass).  Both output buffers 4-byte aligned.  BLOCKING; allocates and frees its scratch (about 20 bytes per
+ * corner) inside the call.  At most 2^31 / 3 triangles. */
+int yakhip_weld_vertices(yakhip_ctx* ctx, const void* triangles_dev, unsigned long long n_triangles, void* vertices_dev,
+                         void* index_dev, unsigned long long* n_vertices_host);
+
 /* ---- cloud extraction --------------------------------------------------- */
 
 /* Replaces kfusion::device::extractCloud (internal.hpp:163; yak/src/cuda/tsdf_volume.cu:464-665, 764-780):

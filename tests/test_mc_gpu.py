@@ -169,3 +169,71 @@ def test_mc_512_volume_fused_on_gpu(gpu_ctx):
     want = oracle.marching_cubes(vol.cpu().numpy().view(np.uint32), dims, 2, vs[0])
     assert len(got) == len(want) > 100000
     assert np.array_equal(canon(got), canon(want))
+
+
+# ---- yakhip_weld_vertices: the exact point merging of MarchingCubesParameters::clean ---------------------------
+
+def numpy_weld(tris):
+    """Distinct corners in ascending (x, y, z) bit-pattern order, and every corner's vertex number."""
+    bits = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 3).view(np.uint32)
+    order = np.lexsort((bits[:, 2], bits[:, 1], bits[:, 0]))
+    s = bits[order]
+    head = np.ones(len(s), dtype=bool)
+    head[1:] = (s[1:] != s[:-1]).any(axis=1)
+    ids = np.cumsum(head) - 1
+    index = np.empty(len(s), dtype=np.uint32)
+    index[order] = ids
+    return s[head], index
+
+
+def gpu_weld(ctx, tris):
+    t = torch.from_numpy(np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 9)).cuda()
+    n = t.shape[0]
+    verts = torch.full((max(3 * n, 1), 3), 7.0, dtype=torch.float32, device="cuda")
+    index = torch.full((max(3 * n, 1),), -1, dtype=torch.int32, device="cuda")
+    nv = ctx.weld_vertices(t.data_ptr(), n, verts.data_ptr(), index.data_ptr())
+    v = verts.cpu().numpy()
+    assert (v[nv:] == 7.0).all()                                          # nothing beyond the count is written
+    return v[:nv].view(np.uint32), index.cpu().numpy().view(np.uint32)[:3 * n]
+
+
+def test_weld_dipyramid(gpu_ctx):
+    vol = np.full(27, 0x00013C00, dtype=np.uint32)
+    vol[13] = 0x0001BC00
+    tris = gpu_mc(gpu_ctx, torch.from_numpy(vol.view(np.int32)).cuda(), (3, 3, 3), 1, 0.01)
+    verts, index = gpu_weld(gpu_ctx, tris)
+    assert len(verts) == 6                                                # test/marching_cubes_tests.cpp:133
+    assert np.array_equal(verts.view(np.float32), DIPYRAMID_VERTICES[np.lexsort(DIPYRAMID_VERTICES.T[::-1])])
+    faces = index.reshape(-1, 3)
+    assert len(faces) == 8 and (faces[:, 0] != faces[:, 1]).all() and (faces[:, 1] != faces[:, 2]).all()
+    # every corner got the vertex with its own bits
+    assert np.array_equal(verts[index], tris.reshape(-1, 3).view(np.uint32))
+
+
+@pytest.mark.parametrize("n,r", [(64, 20.3), (256, 100.7)])
+def test_weld_sphere_equals_numpy(gpu_ctx, n, r):
+    vol = sphere_volume(n, r)
+    tris = gpu_mc(gpu_ctx, torch.from_numpy(vol.view(np.int32)).cuda(), (n, n, n), 1, 0.01)
+    verts, index = gpu_weld(gpu_ctx, tris)
+    want_v, want_i = numpy_weld(tris)
+    assert np.array_equal(verts, want_v) and np.array_equal(index, want_i)
+    assert len(verts) < len(tris) * 3 // 4                                # a closed surface: ~6 corners share a vertex
+
+
+def test_weld_signed_zeros_duplicates_and_edges(gpu_ctx):
+    rng = np.random.default_rng(5)
+    pool = rng.standard_normal((50, 3)).astype(np.float32)
+    pool[0] = (0.0, -0.0, 0.0)                                            # -0.0 and +0.0 are different bit patterns
+    pool[1] = (0.0, 0.0, 0.0)
+    pool[2] = (-1.5, 2.0, np.float32(1e-40))                              # negative (bit 31 set sorts last), subnormal
+    tris = pool[rng.integers(0, 50, size=(1000, 3))]
+    verts, index = gpu_weld(gpu_ctx, tris)
+    want_v, want_i = numpy_weld(tris)
+    assert np.array_equal(verts, want_v) and np.array_equal(index, want_i)
+    # one triangle, three times the same corner; and no triangle at all
+    verts, index = gpu_weld(gpu_ctx, np.ones((1, 3, 3), dtype=np.float32))
+    assert len(verts) == 1 and index.tolist() == [0, 0, 0]
+    assert gpu_ctx.weld_vertices(0, 0, 0, 0) == 0
+    with pytest.raises(capi.YakHipError) as e:
+        gpu_ctx.weld_vertices(0, 5, 0, 0)
+    assert e.value.code == -1

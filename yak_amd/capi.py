@@ -20,7 +20,7 @@ EXPORTS = [
     "yakhip_raycast_points", "yakhip_raycast_depth", "yakhip_raycast_slab", "yakhip_raycast_resolve", "yakhip_raycast_halo",
     "yakhip_bilateral_filter", "yakhip_truncate_depth", "yakhip_depth_pyramid", "yakhip_compute_points_normals",
     "yakhip_resize_points_normals", "yakhip_icp_accumulate", "yakhip_icp_accumulate_rows", "yakhip_icp_estimate",
-    "yakhip_marching_cubes", "yakhip_extract_cloud", "yakhip_extract_normals",
+    "yakhip_marching_cubes", "yakhip_weld_vertices", "yakhip_extract_cloud", "yakhip_extract_normals",
     "yakhip_render_image_points", "yakhip_render_image_depth", "yakhip_render_tangent_colors",
 ]
 
@@ -119,6 +119,7 @@ def load():
         "yakhip_resize_points_normals": [vp, vp, sz, vp, sz, i, i, vp, sz, vp, sz],
         "yakhip_icp_estimate": [vp, fp, fp, fp, C.c_float, C.c_float, C.POINTER(IcpLevel), i, fp, fp, C.POINTER(i)],
         "yakhip_marching_cubes": [vp, volp, i, C.c_double, vp, C.c_ulonglong, C.POINTER(C.c_ulonglong)],
+        "yakhip_weld_vertices": [vp, vp, C.c_ulonglong, vp, vp, C.POINTER(C.c_ulonglong)],
         "yakhip_extract_cloud": [vp, volp, fp, fp, vp, C.c_ulonglong, C.POINTER(C.c_ulonglong)],
         "yakhip_extract_normals": [vp, volp, vp, C.c_ulonglong, fp, fp, fp, C.c_float, vp],
         "yakhip_render_image_points": [vp, vp, sz, vp, sz, i, i, fp, vp, sz],
@@ -337,6 +338,13 @@ class Context:
         n = C.c_ulonglong(0)
         _chk(load().yakhip_marching_cubes(self._h, C.byref(vol), int(min_weight), float(scale),
                                           C.c_void_p(triangles_ptr or 0), int(capacity), C.byref(n)))
+        return n.value
+
+    def weld_vertices(self, triangles_ptr, n_triangles, vertices_ptr, index_ptr):
+        """Blocking.  Merges bit-identical corners; returns the number of distinct vertices written."""
+        n = C.c_ulonglong(0)
+        _chk(load().yakhip_weld_vertices(self._h, C.c_void_p(triangles_ptr or 0), int(n_triangles),
+                                         C.c_void_p(vertices_ptr or 0), C.c_void_p(index_ptr or 0), C.byref(n)))
         return n.value
 
     def extract_cloud(self, vol, R, t, points_ptr=None, capacity=0):

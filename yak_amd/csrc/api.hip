@@ -1181,4 +1181,25 @@ int yakhip_marching_cubes(yakhip_ctx* ctx, const yakhip_volume* vol, int min_wei
                                n_triangles_host);
 }
 
+int yakhip_weld_vertices(yakhip_ctx* ctx, const void* triangles_dev, unsigned long long n_triangles, void* vertices_dev,
+                         void* index_dev, unsigned long long* n_vertices_host)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!n_vertices_host)
+    return fail(YAKHIP_EINVAL, "weld_vertices: null count pointer");
+  *n_vertices_host = 0;
+  if (n_triangles == 0)
+    return 0;
+  if (!triangles_dev || !vertices_dev || !index_dev)
+    return fail(YAKHIP_EINVAL, "weld_vertices: null buffer");
+  if ((uintptr_t)triangles_dev % 4 != 0 || (uintptr_t)vertices_dev % 4 != 0 || (uintptr_t)index_dev % 4 != 0)
+    return fail(YAKHIP_EALIGN, "weld_vertices: buffers must be 4-byte aligned");
+  if (n_triangles > 0x7fffffffull / 3ull)
+    return fail(YAKHIP_ERANGE, "weld_vertices: %llu triangles, at most %llu", n_triangles, 0x7fffffffull / 3ull);
+  return launch_weld(ctx, (const uint32_t*)triangles_dev, (uint32_t)(n_triangles * 3ull), (uint32_t*)vertices_dev,
+                     (uint32_t*)index_dev, n_vertices_host);
+}
+
 }  // extern "C"

@@ -153,6 +153,8 @@ int launch_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], c
 
 // mc.hip (blocking).  `vol` points at layer z0; `layers` voxel layers are present, so layers - 1 cube
 // layers are meshed.  Only counts when triangles == nullptr or the count exceeds `capacity`.
+int launch_weld(yakhip_ctx* ctx, const uint32_t* corners, uint32_t n, uint32_t* vertices, uint32_t* index,
+                unsigned long long* n_vertices_host);
 int launch_marching_cubes(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int z0, int layers, int min_weight,
                           double scale, float* triangles, unsigned long long capacity, unsigned long long* n_out);
 int launch_extract_cloud(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int z0, int layers, const float vs[3],

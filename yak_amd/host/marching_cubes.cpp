@@ -5,9 +5,8 @@
 #include <yak/kfusion/cuda/device_memory.hpp>
 #include <yakhip.h>
 
-#include <algorithm>
-#include <cstring>
-#include <thread>
+#include <cstdint>
+#include <vector>
 
 namespace yak
 {
@@ -30,19 +29,18 @@ PolygonMesh marchingCubesCPU(const TSDFContainer& tsdf, const MarchingCubesParam
   unsigned long long n = 0;
   if (yakhip_marching_cubes(context(), &v, params.min_weight, params.scale, nullptr, 0, &n) != 0)
     error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_marching_cubes(count)");
-  std::vector<float> tri((size_t)n * 9);
-  if (n)
-  {
-    kfusion::cuda::DeviceMemory out((size_t)n * 9 * sizeof(float));
-    unsigned long long m = 0;
-    if (yakhip_marching_cubes(context(), &v, params.min_weight, params.scale, out.ptr<void>(), n, &m) != 0 || m != n)
-      error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_marching_cubes(emit)");
-    out.download(tri.data());
-  }
-
   PolygonMesh mesh;
+  if (n == 0)
+    return mesh;
+  kfusion::cuda::DeviceMemory out((size_t)n * 9 * sizeof(float));
+  unsigned long long m = 0;
+  if (yakhip_marching_cubes(context(), &v, params.min_weight, params.scale, out.ptr<void>(), n, &m) != 0 || m != n)
+    error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_marching_cubes(emit)");
+
   if (!params.clean)  // marching_cubes.cpp:217-220: three fresh points per triangle
   {
+    std::vector<float> tri((size_t)n * 9);
+    out.download(tri.data());
     mesh.cloud.resize((size_t)n * 3);
     mesh.polygons.resize((size_t)n);
     for (size_t i = 0; i < (size_t)n * 3; ++i)
@@ -52,59 +50,20 @@ PolygonMesh marchingCubesCPU(const TSDFContainer& tsdf, const MarchingCubesParam
     return mesh;
   }
 
-  // :204-216 -- exact point merging (bit patterns), then triangles with a repeated index are dropped.
-  // Corners are sorted as packed 16-byte records {x, y, z bits, corner} (contiguous: a sort through an index
-  // array spends its time on cache misses); any strict order on the bit patterns groups equal points.
+  // :204-216 -- exact point merging (bit patterns) on the device: distinct points in ascending order of their
+  // bit patterns and every corner's point (yakhip_weld_vertices: three radix-sort passes instead of the 120 ms
+  // a four-thread host sort of 2.4 M corners took); then triangles with a repeated index are dropped.
   const size_t corners = (size_t)n * 3;
-  struct Corner
-  {
-    std::uint32_t x, y, z, c;
-  };
-  std::vector<Corner> order(corners);
-  for (size_t i = 0; i < corners; ++i)
-  {
-    std::memcpy(&order[i], &tri[i * 3], 12);
-    order[i].c = (std::uint32_t)i;
-  }
-  const auto less = [](const Corner& a, const Corner& b) {
-    if (a.x != b.x)
-      return a.x < b.x;
-    if (a.y != b.y)
-      return a.y < b.y;
-    if (a.z != b.z)
-      return a.z < b.z;
-    return a.c < b.c;
-  };
-  // four sorted quarters on four threads, merged pairwise: the sort is most of this routine's time
-  const size_t parts = corners >= (1u << 16) ? 4 : 1;
-  if (parts == 1)
-    std::sort(order.begin(), order.end(), less);
-  else
-  {
-    size_t cut[5];
-    for (size_t k = 0; k <= 4; ++k)
-      cut[k] = corners * k / 4;
-    std::vector<std::thread> pool;
-    for (size_t k = 0; k < 4; ++k)
-      pool.emplace_back([&, k] { std::sort(order.begin() + cut[k], order.begin() + cut[k + 1], less); });
-    for (auto& t : pool)
-      t.join();
-    std::thread left([&] { std::inplace_merge(order.begin(), order.begin() + cut[1], order.begin() + cut[2], less); });
-    std::inplace_merge(order.begin() + cut[2], order.begin() + cut[3], order.end(), less);
-    left.join();
-    std::inplace_merge(order.begin(), order.begin() + cut[2], order.end(), less);
-  }
+  vol.release();  // the volume copy is not needed any more; the weld's scratch can have its room
+  kfusion::cuda::DeviceMemory verts(corners * 3 * sizeof(float)), index_dev(corners * sizeof(std::uint32_t));
+  unsigned long long nv = 0;
+  if (yakhip_weld_vertices(context(), out.ptr<void>(), n, verts.ptr<void>(), index_dev.ptr<void>(), &nv) != 0)
+    error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_weld_vertices");
+  mesh.cloud.resize((size_t)nv);  // std::array<float, 3>: 12 contiguous bytes a point, as the device wrote them
   std::vector<std::uint32_t> index(corners);
-  mesh.cloud.reserve(corners / 5);
-  for (size_t i = 0; i < corners; ++i)
-  {
-    if (i == 0 || order[i].x != order[i - 1].x || order[i].y != order[i - 1].y || order[i].z != order[i - 1].z)
-    {
-      const float* p = &tri[(size_t)order[i].c * 3];
-      mesh.cloud.push_back({ p[0], p[1], p[2] });
-    }
-    index[order[i].c] = (std::uint32_t)(mesh.cloud.size() - 1);
-  }
+  if (yakhip_download(context(), mesh.cloud.data(), verts.ptr<void>(), (size_t)nv * 3 * sizeof(float)) != 0 ||
+      yakhip_download(context(), index.data(), index_dev.ptr<void>(), index.size() * sizeof(std::uint32_t)) != 0)
+    error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_download(weld)");
   mesh.polygons.reserve((size_t)n);
   for (size_t i = 0; i < (size_t)n; ++i)
   {
