@@ -145,6 +145,18 @@ def next_rows(ctx, torch, capi, synth, with_cpu):
                              "achieved_GBps": round(mc_bytes / (ms * 1e-3) / 1e9, 1),
                              "frac_of_hbm_peak": round(mc_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                              "Gvox_per_s": round(n ** 3 / (ms * 1e-3) / 1e9, 1)}
+    # vertex welding of that triangle list (MarchingCubesParameters::clean): wall time of the blocking call,
+    # scratch allocation included
+    wv = torch.empty((max(3 * ntri, 1), 3), dtype=torch.float32, device="cuda")
+    wi = torch.empty((max(3 * ntri, 1),), dtype=torch.int32, device="cuda")
+    nvert = ctx.weld_vertices(tri.data_ptr(), ntri, wv.data_ptr(), wi.data_ptr())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ctx.weld_vertices(tri.data_ptr(), ntri, wv.data_ptr(), wi.data_ptr())
+    out["marching_cubes"]["weld_vertices"] = {"ms_blocking": round((time.perf_counter() - t0) / 5 * 1e3, 4),
+                                              "corners": 3 * ntri, "vertices": nvert}
+    del wv, wi
     # cloud extraction (count, scan, emit): 2 reads of the volume + 16 B per point
     npts = ctx.extract_cloud(desc, np.eye(3).reshape(-1), np.zeros(3))
     cloud = torch.empty((max(npts, 1), 4), dtype=torch.float32, device="cuda")
