@@ -117,8 +117,14 @@ int main(int argc, char** argv)
     for (int f = 0; f < frames; ++f)
       depth.push_back(render(orbit_pose(f), p.intr, p.rows, p.cols));
 
+    yak::MarchingCubesParameters mc;
+    mc.scale = p.volume_resolution;
+    mc.min_weight = 2;
+    mc.clean = true;
+
     yak::TSDFContainer volume(1, 1, 1);
-    double t0 = 0, t_loop = 0;
+    yak::PolygonMesh direct;  // the mesh taken from the device volume, without the round trip through the host
+    double t0 = 0, t_loop = 0, direct_ms = -1, t_down = 0;
     double worst_mm = 0;
     if (track)
     {  // what a hand-held sensor does: no poses, KinFu tracks by ICP against the ray-cast model
@@ -137,6 +143,7 @@ int main(int argc, char** argv)
       t_loop = now();
       volume = yak::TSDFContainer(n, n, n);
       kinfu.tsdf().data().download(volume.data());
+      t_down = now();
     }
     else
     {  // what yak_ros does: poses come from the robot (TF), FusionServer::fuse per depth image
@@ -152,20 +159,27 @@ int main(int argc, char** argv)
       }
       t_loop = now();
       volume = server.downloadTSDF();
+      t_down = now();
+      direct = server.extractMesh(mc);
+      direct_ms = (now() - t_down) * 1e3;
     }
     const double t1 = now();
 
-    yak::MarchingCubesParameters mc;
-    mc.scale = p.volume_resolution;
-    mc.min_weight = 2;
-    mc.clean = true;
     const yak::PolygonMesh mesh = yak::marchingCubesCPU(volume, mc);
     const double t2 = now();
 
     std::printf("%d^3 volume, %d frames (%s): %.1f ms = %.0f frames/s incl. the upload of every frame; download %.1f ms; "
                 "mesh %.1f ms: %zu vertices, %zu triangles\n",
                 n, frames, track ? "tracked by ICP" : "poses supplied", (t_loop - t0) * 1e3, frames / (t_loop - t0),
-                (t1 - t_loop) * 1e3, (t2 - t1) * 1e3, mesh.cloud.size(), mesh.polygons.size());
+                (t_down - t_loop) * 1e3, (t2 - t1) * 1e3, mesh.cloud.size(), mesh.polygons.size());
+    if (direct_ms >= 0)
+    {
+      const bool same = direct.cloud == mesh.cloud && direct.polygons == mesh.polygons;
+      std::printf("FusionServer::extractMesh (from the device volume): %.1f ms, %s\n", direct_ms,
+                  same ? "the same mesh" : "MESH DIFFERS");
+      if (!same)
+        return 2;
+    }
     if (track)
       std::printf("worst position error against the true orbit: %.1f mm (voxel %.1f mm)\n", worst_mm, 3000.0 / n);
     if (!ply.empty())

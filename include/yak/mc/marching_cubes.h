@@ -36,6 +36,11 @@ struct PolygonMesh
 };
 
 KF_EXPORTS PolygonMesh marchingCubesCPU(const TSDFContainer& tsdf, const MarchingCubesParameters& params = {});
+/** The same mesh from a volume that already lies in device memory (dim_x * dim_y * dim_z packed voxels, x fastest),
+ *  e.g. kfusion::cuda::TsdfVolume::data(): no counterpart in the reference, whose only way to a mesh is
+ *  downloadTSDF() + marchingCubesCPU() -- 512 MiB down and up again at 512^3. */
+KF_EXPORTS PolygonMesh marchingCubesDevice(const void* volume_dev, int dim_x, int dim_y, int dim_z,
+                                           const MarchingCubesParameters& params = {});
 }  // namespace yak
 
 #endif

@@ -9,6 +9,7 @@
 
 #include "yak/kfusion/kinfu.hpp"
 #include "yak/kfusion/tsdf_container.h"
+#include "yak/mc/marching_cubes.h"
 
 #if defined(YAK_USE_EIGEN) && __has_include(<Eigen/Geometry>)
 #include <Eigen/Geometry>
@@ -36,6 +37,9 @@ public:
    *  device volume by `volume`, e.g. to resume a fusion that was saved.  Returns false, touching nothing,
    *  if the dimensions differ from the server's volume.  Tracking continues from the poses it had. */
   bool uploadTSDF(const yak::TSDFContainer& volume);
+  /** marchingCubesCPU(downloadTSDF(), params) without the round trip through host memory: the mesh is extracted
+   *  (and, with params.clean, welded) from the volume where it lies (no counterpart in the reference). */
+  yak::PolygonMesh extractMesh(const yak::MarchingCubesParameters& params = {});
   /** Renders the tracker's current model view (Phong | normal colours, rows x 2 cols) and downloads it
    *  (yak_server.cpp:100-104); the reference then shows it in a window. */
   void display();

@@ -10,18 +10,15 @@
 
 namespace yak
 {
-PolygonMesh marchingCubesCPU(const TSDFContainer& tsdf, const MarchingCubesParameters& params)
+PolygonMesh marchingCubesDevice(const void* volume_dev, int dim_x, int dim_y, int dim_z,
+                                const MarchingCubesParameters& params)
 {
   using kfusion::cuda::context;
   using kfusion::cuda::error;
-  const Vector3i d = tsdf.dims();
-  kfusion::cuda::DeviceMemory vol;
-  vol.upload(tsdf.data(), tsdf.size64() * sizeof(std::uint32_t));
-
   yakhip_volume v;
-  v.data = vol.ptr<void>();
-  v.dims[0] = d.x(), v.dims[1] = d.y(), v.dims[2] = d.z();
-  v.z0 = 0, v.z1 = d.z();
+  v.data = const_cast<void*>(volume_dev);
+  v.dims[0] = dim_x, v.dims[1] = dim_y, v.dims[2] = dim_z;
+  v.z0 = 0, v.z1 = dim_z;
   v.voxel_size[0] = v.voxel_size[1] = v.voxel_size[2] = 1.f;  // vertices are in voxel units times params.scale
   v.trunc_dist = 1.f;
   v.max_weight = 1;
@@ -54,7 +51,6 @@ PolygonMesh marchingCubesCPU(const TSDFContainer& tsdf, const MarchingCubesParam
   // bit patterns and every corner's point (yakhip_weld_vertices: three radix-sort passes instead of the 120 ms
   // a four-thread host sort of 2.4 M corners took); then triangles with a repeated index are dropped.
   const size_t corners = (size_t)n * 3;
-  vol.release();  // the volume copy is not needed any more; the weld's scratch can have its room
   kfusion::cuda::DeviceMemory verts(corners * 3 * sizeof(float)), index_dev(corners * sizeof(std::uint32_t));
   unsigned long long nv = 0;
   if (yakhip_weld_vertices(context(), out.ptr<void>(), n, verts.ptr<void>(), index_dev.ptr<void>(), &nv) != 0)
@@ -72,5 +68,13 @@ PolygonMesh marchingCubesCPU(const TSDFContainer& tsdf, const MarchingCubesParam
       mesh.polygons.push_back({ a, b, c });
   }
   return mesh;
+}
+
+PolygonMesh marchingCubesCPU(const TSDFContainer& tsdf, const MarchingCubesParameters& params)
+{
+  const Vector3i d = tsdf.dims();
+  kfusion::cuda::DeviceMemory vol;
+  vol.upload(tsdf.data(), tsdf.size64() * sizeof(std::uint32_t));
+  return marchingCubesDevice(vol.ptr<void>(), d.x(), d.y(), d.z(), params);
 }
 }  // namespace yak

@@ -105,6 +105,13 @@ bool FusionServer::resetWithNewParams(const kfusion::KinFuParams& params)
 }
 
 // yak_server.cpp:67-76
+yak::PolygonMesh FusionServer::extractMesh(const yak::MarchingCubesParameters& params)
+{
+  const kfusion::cuda::TsdfVolume& vol = kinfu_->tsdf();
+  const kfusion::Vec3i dims = vol.getDims();
+  return yak::marchingCubesDevice(vol.data().ptr<void>(), dims[0], dims[1], dims[2], params);
+}
+
 yak::TSDFContainer FusionServer::downloadTSDF()
 {
   const kfusion::cuda::TsdfVolume& vol = kinfu_->tsdf();
