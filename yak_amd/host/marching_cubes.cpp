@@ -5,7 +5,10 @@
 #include <yak/kfusion/cuda/device_memory.hpp>
 #include <yakhip.h>
 
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace yak
@@ -23,9 +26,21 @@ PolygonMesh marchingCubesDevice(const void* volume_dev, int dim_x, int dim_y, in
   v.trunc_dist = 1.f;
   v.max_weight = 1;
 
+  // YAK_MC_TIMING=1: where the call's time goes, on stderr
+  const bool timing = std::getenv("YAK_MC_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  const auto lap = [&](const char* what) {
+    if (!timing)
+      return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "marchingCubesDevice: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+    t_last = t;
+  };
+
   unsigned long long n = 0;
   if (yakhip_marching_cubes(context(), &v, params.min_weight, params.scale, nullptr, 0, &n) != 0)
     error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_marching_cubes(count)");
+  lap("count pass");
   PolygonMesh mesh;
   if (n == 0)
     return mesh;
@@ -33,6 +48,7 @@ PolygonMesh marchingCubesDevice(const void* volume_dev, int dim_x, int dim_y, in
   unsigned long long m = 0;
   if (yakhip_marching_cubes(context(), &v, params.min_weight, params.scale, out.ptr<void>(), n, &m) != 0 || m != n)
     error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_marching_cubes(emit)");
+  lap("allocate + emit pass");
 
   if (!params.clean)  // marching_cubes.cpp:217-220: three fresh points per triangle
   {
@@ -55,11 +71,13 @@ PolygonMesh marchingCubesDevice(const void* volume_dev, int dim_x, int dim_y, in
   unsigned long long nv = 0;
   if (yakhip_weld_vertices(context(), out.ptr<void>(), n, verts.ptr<void>(), index_dev.ptr<void>(), &nv) != 0)
     error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_weld_vertices");
+  lap("allocate + weld");
   mesh.cloud.resize((size_t)nv);  // std::array<float, 3>: 12 contiguous bytes a point, as the device wrote them
   std::vector<std::uint32_t> index(corners);
   if (yakhip_download(context(), mesh.cloud.data(), verts.ptr<void>(), (size_t)nv * 3 * sizeof(float)) != 0 ||
       yakhip_download(context(), index.data(), index_dev.ptr<void>(), index.size() * sizeof(std::uint32_t)) != 0)
     error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_download(weld)");
+  lap("download vertices + indices");
   mesh.polygons.reserve((size_t)n);
   for (size_t i = 0; i < (size_t)n; ++i)
   {
@@ -67,6 +85,7 @@ PolygonMesh marchingCubesDevice(const void* volume_dev, int dim_x, int dim_y, in
     if (a != b && b != c && a != c)
       mesh.polygons.push_back({ a, b, c });
   }
+  lap("drop degenerate triangles");
   return mesh;
 }
 
