@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--rank", type=int, default=3)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--z-chunk", type=int, default=0, help="layers per workgroup walk (0 = the library's choice)")
     args = ap.parse_args()
     import torch
 
@@ -28,6 +29,8 @@ def main():
     from yak_amd.shard import slab_range
 
     ctx = capi.Context(0)
+    if args.z_chunk:
+        ctx.set_option("z_chunk", args.z_chunk)
     n = args.n
     dims, vs, tr = synth.volume_geometry(n)
     z0, z1 = slab_range(n, args.world, args.rank)

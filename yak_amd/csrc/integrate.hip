@@ -929,7 +929,13 @@ int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in)
   // Layers of 4 MiB and more (the slabs of a 1024-wide volume) stream better in shorter walks: with no
   // arithmetic at all an in-place sweep of 1024 x 1024 x 128 takes 201 us in 32-layer walks and 188 us in
   // 16-layer walks (tools/rmw.hip; 512 x 512 x 512: 183 us); this kernel 0.203 -> 0.198 ms.
-  const int min_chunk = (uint64_t)p.plane * 4u >= (4ull << 20) ? 16 : 32;
+  // Not beyond that: with layers of 16 MiB (a 2048-wide slab) every walk is 4096 workgroups, each with its own
+  // set-up (19 KB of coarse minima into LDS, checkpoint, descriptor), and on frames with surfaces -- where the
+  // kernel is bound by instructions, not by the sweep -- 16-layer walks cost more than they stream better:
+  // four single-frame calls on the orbit rig over a 2048 x 2048 x 256 slab take 7.9 ms in 16-layer walks, 6.7 in
+  // 32-layer and 6.1 in 64-layer ones (tools/bench_c5.py --z-chunk), the bare sweep 209 / 231 us per 2^27 voxels.
+  const uint64_t layer_bytes = (uint64_t)p.plane * 4u;
+  const int min_chunk = layer_bytes >= (4ull << 20) && layer_bytes < (16ull << 20) ? 16 : 32;
   if ((rc = choose_chunk(ctx, p, blocks_x, 768u, min_chunk, &chunk, &nchunks)) != 0)
     return rc;
   p.z_chunk = chunk;
