@@ -94,6 +94,11 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value);
  * hipEvent pair on the context's stream; this call waits for them, returns the summed device time of
  * those launches (milliseconds) and their count, and restarts the accumulation. */
 int yakhip_ctx_kernel_time(yakhip_ctx* ctx, double* total_ms, int* launches);
+/* The same accumulation launch by launch (also without counterpart in the reference): ms_out[i] = device time
+ * of the i-th bracketed launch, start_ms_out[i] (may be NULL) = time from the first bracketed launch's start to
+ * this one's start, for the first min(*launches, capacity) launches; *launches = how many were bracketed.
+ * Restarts the accumulation.  bench.py prints this series so that slow launches can be told from the mean. */
+int yakhip_ctx_kernel_times(yakhip_ctx* ctx, float* ms_out, float* start_ms_out, int capacity, int* launches);
 /* Device self-test with no counterpart in the reference: the integrate kernel replaces IEEE '/' by a
  * v_rcp_f32 + Newton + Markstein sequence; this checks on the GPU at hand that (a) the refined
  * reciprocal is the correctly rounded 1/d for all 2^23 mantissas at 8 exponents and (b) the quotient

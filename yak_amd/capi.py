@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libyakhip.so")
 EXPORTS = [
     "yakhip_ctx_create", "yakhip_ctx_destroy", "yakhip_ctx_set_stream", "yakhip_ctx_use_own_stream", "yakhip_ctx_synchronize",
     "yakhip_device_count", "yakhip_device_name", "yakhip_last_error", "yakhip_ctx_set_option",
-    "yakhip_ctx_kernel_time", "yakhip_selftest_division",
+    "yakhip_ctx_kernel_time", "yakhip_ctx_kernel_times", "yakhip_selftest_division",
     "yakhip_malloc", "yakhip_malloc_pitch", "yakhip_free", "yakhip_upload", "yakhip_download",
     "yakhip_upload_2d", "yakhip_download_2d", "yakhip_copy", "yakhip_copy_2d",
     "yakhip_clear_volume", "yakhip_compute_dists", "yakhip_integrate", "yakhip_integrate_batch",
@@ -91,6 +91,7 @@ def load():
         "yakhip_device_name": [i, C.c_char_p, sz],
         "yakhip_ctx_set_option": [vp, C.c_char_p, i],
         "yakhip_ctx_kernel_time": [vp, C.POINTER(C.c_double), C.POINTER(i)],
+        "yakhip_ctx_kernel_times": [vp, fp, fp, i, C.POINTER(i)],
         "yakhip_selftest_division": [vp, C.POINTER(C.c_ulonglong)],
         "yakhip_malloc": [vp, C.POINTER(vp), sz],
         "yakhip_malloc_pitch": [vp, C.POINTER(vp), C.POINTER(sz), sz, sz],
@@ -194,6 +195,13 @@ class Context:
         ms, n = C.c_double(0.0), C.c_int(0)
         _chk(load().yakhip_ctx_kernel_time(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def kernel_times(self, capacity=4096):
+        """Per-launch (device ms, start offset ms) lists of the bracketed launches since kernel_timing was set."""
+        ms, st, n = (C.c_float * capacity)(), (C.c_float * capacity)(), C.c_int(0)
+        _chk(load().yakhip_ctx_kernel_times(self._h, ms, st, capacity, C.byref(n)))
+        k = min(n.value, capacity)
+        return list(ms[:k]), list(st[:k])
 
     def selftest_division(self):
         out = (C.c_ulonglong * 4)()

@@ -299,6 +299,27 @@ int yakhip_ctx_kernel_time(yakhip_ctx* ctx, double* total_ms, int* launches)
   return 0;
 }
 
+int yakhip_ctx_kernel_times(yakhip_ctx* ctx, float* ms_out, float* start_ms_out, int capacity, int* launches)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!launches || capacity < 0 || (capacity > 0 && !ms_out))
+    return fail(YAKHIP_EINVAL, "kernel_times: null out pointer or negative capacity");
+  for (size_t i = 0; i < ctx->timing_used; ++i)
+  {
+    YAKHIP_TRY(hipEventSynchronize(ctx->timing_events[i].second));
+    if ((int)i >= capacity)
+      continue;
+    YAKHIP_TRY(hipEventElapsedTime(&ms_out[i], ctx->timing_events[i].first, ctx->timing_events[i].second));
+    if (start_ms_out)
+      YAKHIP_TRY(hipEventElapsedTime(&start_ms_out[i], ctx->timing_events[0].first, ctx->timing_events[i].first));
+  }
+  *launches = (int)ctx->timing_used;
+  ctx->timing_used = 0;
+  return 0;
+}
+
 int yakhip_selftest_division(yakhip_ctx* ctx, unsigned long long counts[4])
 {
   int rc = enter(ctx);
