@@ -145,6 +145,22 @@ int yakhip_compute_dists(yakhip_ctx* ctx, const void* depth_dev, size_t depth_pi
 int yakhip_integrate(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dists_dev, size_t dists_pitch, int rows,
                      int cols, const float R[9], const float t[3], const float intr[4]);
 
+/* yakhip_integrate for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for code
+ * under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments, same
+ * kernels and the same voxels, bit for bit, as yakhip_integrate; the per-frame scratch (band thresholds,
+ * coarse minima, and the column checkpoints of a slab with z0 >= 64) lives in a file-scope __device__ array of
+ * the library instead of context-owned buffers -- about 20 MiB per GPU, held until the process ends, its
+ * address taken once in yakhip_ctx_create -- and the call itself performs no hipMalloc / hipFree / event
+ * creation (the "kernel_timing" option is ignored here).
+ * Limits: rows * cols <= YAKHIP_STATIC_MAX_PIXELS, else YAKHIP_ERANGE; a slab with z0 >= 64 whose plane
+ * dims[0] * dims[1] exceeds YAKHIP_STATIC_MAX_COLUMNS replays the reference's additions from layer 0
+ * (same result, slower start).  Every call on one GPU shares that GPU's array, in every context: calls that
+ * overlap on one GPU (two streams, two threads) race; calls on one stream are ordered and safe. */
+#define YAKHIP_STATIC_MAX_PIXELS (1u << 20)
+#define YAKHIP_STATIC_MAX_COLUMNS (1u << 20)
+int yakhip_integrate_static(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dists_dev, size_t dists_pitch,
+                            int rows, int cols, const float R[9], const float t[3], const float intr[4]);
+
 /* One camera frame of a batch: its ray-distance image (as yakhip_compute_dists writes it), vol2cam pose
  * and intrinsics -- the arguments kfusion::device::integrate takes per frame (internal.hpp:126). */
 typedef struct yakhip_frame

@@ -16,7 +16,8 @@ EXPORTS = [
     "yakhip_ctx_kernel_time", "yakhip_ctx_kernel_times", "yakhip_selftest_division",
     "yakhip_malloc", "yakhip_malloc_pitch", "yakhip_free", "yakhip_upload", "yakhip_download",
     "yakhip_upload_2d", "yakhip_download_2d", "yakhip_copy", "yakhip_copy_2d",
-    "yakhip_clear_volume", "yakhip_compute_dists", "yakhip_integrate", "yakhip_integrate_batch",
+    "yakhip_clear_volume", "yakhip_compute_dists", "yakhip_integrate", "yakhip_integrate_static",
+    "yakhip_integrate_batch",
     "yakhip_raycast_points", "yakhip_raycast_depth", "yakhip_raycast_slab", "yakhip_raycast_resolve", "yakhip_raycast_halo",
     "yakhip_bilateral_filter", "yakhip_truncate_depth", "yakhip_depth_pyramid", "yakhip_compute_points_normals",
     "yakhip_resize_points_normals", "yakhip_icp_accumulate", "yakhip_icp_accumulate_rows", "yakhip_icp_estimate",
@@ -105,6 +106,7 @@ def load():
         "yakhip_clear_volume": [vp, volp],
         "yakhip_compute_dists": [vp, vp, sz, vp, sz, i, i, fp],
         "yakhip_integrate": [vp, volp, vp, sz, i, i, fp, fp, fp],
+        "yakhip_integrate_static": [vp, volp, vp, sz, i, i, fp, fp, fp],
         "yakhip_integrate_batch": [vp, volp, C.POINTER(FrameDesc), i],
         "yakhip_raycast_points": [vp, volp, fp, fp, fp, fp, C.c_float, C.c_float, vp, sz, vp, sz, i, i],
         "yakhip_raycast_depth": [vp, volp, fp, fp, fp, fp, C.c_float, C.c_float, vp, sz, vp, sz, i, i],
@@ -222,6 +224,11 @@ class Context:
     def integrate(self, vol, dists_ptr, dists_pitch, rows, cols, R, t, intr):
         _chk(load().yakhip_integrate(self._h, C.byref(vol), C.c_void_p(dists_ptr), dists_pitch, rows, cols,
                                      _f32(R, 9), _f32(t, 3), _f32(intr, 4)))
+
+    def integrate_static(self, vol, dists_ptr, dists_pitch, rows, cols, R, t, intr):
+        """yakhip_integrate without any allocation in the call (scratch in the library's file-scope array)."""
+        _chk(load().yakhip_integrate_static(self._h, C.byref(vol), C.c_void_p(dists_ptr), dists_pitch, rows, cols,
+                                            _f32(R, 9), _f32(t, 3), _f32(intr, 4)))
 
     def integrate_batch(self, vol, frames):
         """frames: sequence of (dists_ptr, dists_pitch, rows, cols, R, t, intr), applied in order."""

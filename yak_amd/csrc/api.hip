@@ -130,6 +130,7 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->thr_bytes = 0;
   ctx->ckpt = nullptr;
   ctx->ckpt_bytes = 0;
+  ctx->static_scratch = nullptr;
   ctx->icp_scratch = nullptr;
   ctx->icp_scratch_bytes = 0;
   ctx->icp_pinned = nullptr;
@@ -147,6 +148,14 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
     return rc;
   }
   ctx->stream = ctx->own_stream;
+  // set-up for yakhip_integrate_static: this device's address of the library's file-scope scratch array,
+  // asked for once per context with the context's device current (each GPU holds its own copy)
+  if ((rc = static_scratch_address(&ctx->static_scratch)) != 0)
+  {
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return rc;
+  }
   *out = ctx;
   return 0;
 }
@@ -650,6 +659,20 @@ int yakhip_integrate(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dist
   if ((rc = fill_integrate_params(p, vol, dists_dev, dists_pitch, rows, cols, R, t, intr)) != 0)
     return rc;
   return launch_integrate(ctx, p);
+}
+
+int yakhip_integrate_static(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dists_dev, size_t dists_pitch,
+                            int rows, int cols, const float R[9], const float t[3], const float intr[4])
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_volume(vol)) != 0)
+    return rc;
+  IntegrateParams p;
+  if ((rc = fill_integrate_params(p, vol, dists_dev, dists_pitch, rows, cols, R, t, intr)) != 0)
+    return rc;
+  return launch_integrate(ctx, p, true);
 }
 
 int yakhip_integrate_batch(yakhip_ctx* ctx, const yakhip_volume* vol, const yakhip_frame* frames, int n_frames)

@@ -730,12 +730,12 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
 }
 
 template <int VX>
-static int launch_variant(yakhip_ctx* ctx, const IntegrateParams& p, dim3 grid)
+static int launch_variant(yakhip_ctx* ctx, const IntegrateParams& p, dim3 grid, bool use_static)
 {
   const size_t lds = VX == 4 && p.grp_enable ? (size_t)p.cw * p.ch * sizeof(float) : 0;
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-  int rc = timing_begin(ctx, &ev);  // measurement aid: one event pair around this kernel only
-  if (rc != 0)
+  int rc = use_static ? 0 : timing_begin(ctx, &ev);  // measurement aid: one event pair around this kernel only
+  if (rc != 0)                                       // (it may create events: not on the allocation-free path)
     return rc;
   if (ctx->nontemporal)
     hipLaunchKernelGGL((integrate_kernel<VX, true>), grid, dim3(256), lds, ctx->stream, p);
@@ -746,12 +746,42 @@ static int launch_variant(yakhip_ctx* ctx, const IntegrateParams& p, dim3 grid)
   return check(hipGetLastError(), "integrate_kernel launch");
 }
 
+// ---- scratch of the allocation-free entry point (yakhip_integrate_static) -----------------------
+// One array per GPU, held until the process ends: [band thresholds | coarse minima] of one frame, then the
+// column checkpoints of a deep slab.  Host code never uses the array's name as an address (it is a host-side
+// stand-in): static_scratch_address() asks the runtime for the device address once per device and the
+// launchers pass that pointer on, exactly as they pass the context-owned buffers of yakhip_integrate.
+// Nothing in it has to start at zero: the prepass of a call writes every word the call's kernel reads.
+constexpr size_t kStaticMaxPixels = YAKHIP_STATIC_MAX_PIXELS;    // image of the frame
+constexpr size_t kStaticMaxColumns = YAKHIP_STATIC_MAX_COLUMNS;  // X * Y up to which a deep slab gets checkpoints
+constexpr size_t kStaticCoarseCap = 32768;
+constexpr size_t kStaticFrameBytes = kStaticMaxPixels * sizeof(f32x2) + kStaticCoarseCap;
+constexpr size_t kStaticCkptBytes = kStaticMaxColumns * 3u * sizeof(float);
+static __device__ __align__(256) unsigned char scratch[kStaticFrameBytes + kStaticCkptBytes];
+
+int static_scratch_address(void** out)
+{
+  void* ptr = nullptr;
+  YAKHIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));  // of the CURRENT device's copy
+  if (!ptr)
+    return fail(YAKHIP_EINVAL, "hipGetSymbolAddress(scratch) returned a null pointer");
+  *out = ptr;
+  return 0;
+}
+
 // scratch for the column checkpoints of slot `slot` (see checkpoint_column); sets p.ckpt or leaves it null
-static int prepare_checkpoint(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slots)
+static int prepare_checkpoint(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slots, bool use_static)
 {
   p.ckpt = nullptr;
   if (p.z0 < kCheckpointFrom || !ctx->checkpoint)
     return 0;
+  if (use_static)
+  {
+    // a plane beyond the array's share replays from layer 0 instead: same voxels, slower start
+    if ((size_t)p.plane <= kStaticMaxColumns)
+      p.ckpt = (const float*)((char*)ctx->static_scratch + kStaticFrameBytes);
+    return 0;
+  }
   const size_t slot_bytes = ((size_t)p.plane * 3u * sizeof(float) + 255u) & ~(size_t)255u;
   if (ctx->ckpt_bytes < slot_bytes * (size_t)slots)
   {
@@ -772,7 +802,8 @@ static int prepare_checkpoint(yakhip_ctx* ctx, IntegrateParams& p, int slot, int
 // Per-frame set-up shared by the single-frame and the batched launch: the prepass kernel (band
 // thresholds + coarse minima) into slot `slot` of the context's scratch, and the group-test constants.
 // All slots of one launch have the same geometry (same image size, same coarse cap).
-static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slots, size_t coarse_cap_bytes)
+static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slots, size_t coarse_cap_bytes,
+                         bool use_static = false)
 {
   // ---- per-frame prepass into context-owned scratch: per-pixel band thresholds (8 B/pixel) and
   //      the coarse minima the group test looks up (one float per bk x bk pixel cell) ----
@@ -784,7 +815,15 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
   const size_t thr_bytes = (size_t)p.rows * (size_t)p.cols * sizeof(f32x2);
   const size_t coarse_bytes = (size_t)p.cw * p.ch * sizeof(float);
   const size_t slot_bytes = (thr_bytes + coarse_bytes + 255u) & ~(size_t)255u;
-  if (ctx->thr_bytes < slot_bytes * (size_t)slots)
+  if (use_static)
+  {
+    if (!ctx->static_scratch)
+      return fail(YAKHIP_EINVAL, "integrate_static: the context holds no address of the static scratch");
+    if ((size_t)p.rows * (size_t)p.cols > kStaticMaxPixels || coarse_bytes > kStaticCoarseCap)
+      return fail(YAKHIP_ERANGE, "integrate_static: a %d x %d image exceeds the static scratch (at most %zu pixels)",
+                  p.cols, p.rows, kStaticMaxPixels);
+  }
+  else if (ctx->thr_bytes < slot_bytes * (size_t)slots)
   {
     if (slot != 0)
       return fail(YAKHIP_EINVAL, "integrate: frames of one batch must have the same image size");
@@ -798,11 +837,11 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
     YAKHIP_TRY(hipMalloc(&ctx->thr, slot_bytes * (size_t)slots));
     ctx->thr_bytes = slot_bytes * (size_t)slots;
   }
-  char* base = (char*)ctx->thr + slot_bytes * (size_t)slot;
+  char* base = use_static ? (char*)ctx->static_scratch : (char*)ctx->thr + slot_bytes * (size_t)slot;
   p.thr = (const f32x2*)base;
   p.coarse = (const float*)(base + thr_bytes);
   {
-    const int rc = prepare_checkpoint(ctx, p, slot, slots);
+    const int rc = prepare_checkpoint(ctx, p, slot, slots, use_static);
     if (rc != 0)
       return rc;
     const uint32_t thr_blocks_x = (uint32_t)((p.cols + 255) / 256);
@@ -903,11 +942,11 @@ static int choose_tile(const yakhip_ctx* ctx, const IntegrateParams& p, int vx)
   return shift;
 }
 
-int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in)
+int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in, bool use_static)
 {
   IntegrateParams p = p_in;
   const uintptr_t base = (uintptr_t)p.vol;
-  int rc = prepare_frame(ctx, p, 0, 1, 32768);
+  int rc = prepare_frame(ctx, p, 0, 1, 32768, use_static);
   if (rc != 0)
     return rc;
 
@@ -945,11 +984,11 @@ int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in)
   switch (vx)
   {
     case 4:
-      return launch_variant<4>(ctx, p, grid);
+      return launch_variant<4>(ctx, p, grid, use_static);
     case 2:
-      return launch_variant<2>(ctx, p, grid);
+      return launch_variant<2>(ctx, p, grid, use_static);
     default:
-      return launch_variant<1>(ctx, p, grid);
+      return launch_variant<1>(ctx, p, grid, use_static);
   }
 }
 

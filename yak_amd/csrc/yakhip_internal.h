@@ -26,6 +26,7 @@ struct yakhip_ctx
   size_t thr_bytes;
   void* ckpt;          // scratch: column positions at layer z0 of a deep slab (integrate.hip, checkpoint_kernel)
   size_t ckpt_bytes;
+  void* static_scratch;  // this device's copy of integrate.hip's file-scope scratch array (yakhip_integrate_static)
   void* icp_scratch;   // ICP: workgroup partials + the reduced 33 values (device)
   size_t icp_scratch_bytes;
   void* icp_pinned;    // ICP: pinned host mirror of the 33 values
@@ -114,7 +115,11 @@ struct RaycastParams
   int z_base, z_held, z_own0, z_own1;
 };
 
-int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p);
+// use_static: thresholds / checkpoints go to the file-scope array instead of context-owned buffers, and the
+// call neither allocates nor creates events (yakhip_integrate_static)
+int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p, bool use_static = false);
+// device address of the CURRENT device's copy of that array (hipGetSymbolAddress; once per context)
+int static_scratch_address(void** out);
 // n_frames >= 1 frames applied in order to the same slab; thr / coarse / grp_* / z_chunk are filled here
 int launch_integrate_batch(yakhip_ctx* ctx, const IntegrateParams* frames, int n_frames);
 int launch_raycast(yakhip_ctx* ctx, const RaycastParams& p);
