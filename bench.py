@@ -232,6 +232,8 @@ def main():
     ap.add_argument("--vx", type=int, default=0, help="cap on voxels per lane (tuning)")
     ap.add_argument("--tile", type=int, default=0, help="wave footprint: log2 lanes along x, 3..6 (tuning)")
     ap.add_argument("--zu", type=int, default=0, help="layers per loop trip (tuning)")
+    ap.add_argument("--stacked", action="store_true", help="waves of a workgroup stacked in y instead of side by side (tuning)")
+    ap.add_argument("--no-brick", action="store_true", help="switch the whole-brick test off (tuning)")
     ap.add_argument("--no-nt", action="store_true", help="plain instead of non-temporal volume accesses (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rows", action="store_true", help="skip the secondary measurements (raycast, ICP, MC, batch)")
@@ -301,6 +303,10 @@ def main():
         ctx.set_option("tile", args.tile)
     if args.zu:
         ctx.set_option("zu", args.zu)
+    if args.no_brick:
+        ctx.set_option("brick_test", 0)
+    if args.stacked:
+        ctx.set_option("tile_side", 0)
     if args.no_nt:
         ctx.set_option("nontemporal", 0)
     d_depth = torch.from_numpy(depth.view(np.int16)).cuda()

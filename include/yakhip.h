@@ -82,9 +82,10 @@ int yakhip_device_name(int device, char* buf, size_t buflen);
 const char* yakhip_last_error(void);
 /* Engine knobs that are not part of the reference's API (results never depend on them).  Keys:
  * "z_chunk" (layers walked by one workgroup, 0 = auto), "nontemporal" (0/1), "vx" (cap on voxels per
- * lane: 0 = widest, 1, 2, 4), "group_test" (0/1: coarse culling test of whole voxel runs),
+ * lane: 0 = widest, 1, 2, 4), "group_test" (0/1: coarse culling test of whole voxel runs), "brick_test" (0/1:
+ * whole workgroup bricks that cannot update, or update everywhere with tsdf 1, are settled before they are walked),
  * "checkpoint" (0/1: slabs with z0 >= 64 start from column positions computed in closed form instead of
- * replaying z0 additions per column), "tile" (0 or 3..6: wave footprint in the layer), "mc_z_chunk"
+ * replaying z0 additions per column), "tile" (0 or 3..6: wave footprint in the layer), "tile_side" (0/1: a workgroup's waves stacked in y / side by side in x), "mc_z_chunk"
  * (marching-cubes tile depth, 0 = auto), "kernel_timing" (0/1, see yakhip_ctx_kernel_time), "zu" (ignored).
  * Unknown key or value -> YAKHIP_EINVAL. */
 int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value);

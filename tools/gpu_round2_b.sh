@@ -1,0 +1,26 @@
+#!/bin/bash
+# brick test: parity, then A/B timings (each step under its own limit; stops at the first abnormal end)
+set -u
+mkdir -p gpurun_out
+step() { local name=$1 lim=$2; shift 2
+  timeout -k 10 "$lim" "$@" > "gpurun_out/$name.out" 2> "gpurun_out/$name.err"; local rc=$?
+  echo "$name rc=$rc"; if [ $rc -ne 0 ] && [ $rc -ne 1 ]; then echo "stopping after $name"; exit $rc; fi; }
+step parity 600 python -u -m pytest tests/test_integrate_gpu.py tests/test_integrate_batch_gpu.py tests/test_zz_no_alloc.py -x -q --timeout 300 --timeout-method thread
+tail -3 gpurun_out/parity.out
+B="python bench.py --steps 100 --warmup 10 --no-rows --no-cpu-baseline"
+for sc in s0 s1 s2; do
+  step b_${sc}_nobrick 120 $B --scene $sc --no-brick
+  step b_${sc}_brick 120 $B --scene $sc
+  step b_${sc}_brick_t4 120 $B --scene $sc --tile 4
+  step b_${sc}_brick_t6 120 $B --scene $sc --tile 6
+  step b_${sc}_brick_c16 120 $B --scene $sc --z-chunk 16
+done
+step b_s0_nobrick_t3 120 $B --scene s0 --no-brick --tile 3
+for f in gpurun_out/b_*.out; do python - $f <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d['roofline']
+    print(sys.argv[1].split('/')[-1], 'kernel_ms', r['kernel_ms'], 'steady', r['steady_state']['kernel_ms'], 'step', r['step_ms_device'], 'value', d['value'])
+except Exception as e: print(sys.argv[1], 'ERR', e)
+PY
+done

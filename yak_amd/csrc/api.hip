@@ -123,8 +123,10 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->force_vx = 0;
   ctx->zu = 0;
   ctx->group_test = 1;
+  ctx->brick_test = 1;
   ctx->checkpoint = 1;
   ctx->tile_shift = 0;
+  ctx->tile_side = 1;
   ctx->mc_z_chunk = 0;
   ctx->thr = nullptr;
   ctx->thr_bytes = 0;
@@ -258,6 +260,11 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
     ctx->group_test = value != 0;
     return 0;
   }
+  if (strcmp(key, "brick_test") == 0)
+  {
+    ctx->brick_test = value != 0;
+    return 0;
+  }
   if (strcmp(key, "checkpoint") == 0)
   {
     ctx->checkpoint = value != 0;
@@ -268,6 +275,11 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
     if (value != 0 && (value < 3 || value > 6))
       return fail(YAKHIP_EINVAL, "tile must be 0 (default) or 3..6");
     ctx->tile_shift = value;
+    return 0;
+  }
+  if (strcmp(key, "tile_side") == 0)
+  {
+    ctx->tile_side = value != 0;
     return 0;
   }
   if (strcmp(key, "mc_z_chunk") == 0)
@@ -630,6 +642,7 @@ static int fill_integrate_params(IntegrateParams& p, const yakhip_volume* vol, c
   p.z1 = vol->z1;
   p.z_chunk = 0;
   p.tile_shift = 6;
+  p.tile_side = 1;
   p.plane = (uint32_t)vol->dims[0] * (uint32_t)vol->dims[1];
   p.vsx = vol->voxel_size[0];
   p.vsy = vol->voxel_size[1];

@@ -192,6 +192,7 @@ __device__ __forceinline__ f32x2 band_thresholds(float Dp, float trunc_hi)
 // frame, in closed form (ffwd.hpp: bit-identical to the loop), by extra workgroups of the prepass launch,
 // and the integrate kernels start from that.
 constexpr int kCheckpointFrom = 64;  // slabs starting below this layer replay from 0 as before
+constexpr int kBrickCell = 16;       // pixels per side of a brick-test cell (prepass_kernel, classify_brick)
 
 __device__ __forceinline__ void checkpoint_column(const IntegrateParams& p, float* out, uint32_t col)
 {
@@ -219,7 +220,8 @@ __global__ __launch_bounds__(256) void prepass_kernel(const uint8_t* dists, uint
                                                       float trunc_hi, f32x2* thr, float* coarse, int cw, int ch,
                                                       int bk, uint32_t thr_blocks_x, uint32_t thr_blocks,
                                                       uint32_t ckpt_blocks, const IntegrateParams cp,
-                                                      float* ckpt_out)
+                                                      float* ckpt_out, float* cellmin, float* cellmax, int ccw, int cch,
+                                                      uint32_t coarse_blocks)
 {
   // the column checkpoints of a deep slab are the long job of this launch: its workgroups come first, the
   // image's fill in behind them (ckpt_blocks = 0 for a slab that replays from layer 0)
@@ -245,10 +247,45 @@ __global__ __launch_bounds__(256) void prepass_kernel(const uint8_t* dists, uint
     thr[(size_t)y * cols + x] = ab;
     return;
   }
+  const int lane = (int)(threadIdx.x & 63u);
+  if (bid >= thr_blocks + coarse_blocks)
+  {
+    // brick test planes: min A2 / max B2 word over the pixels of each kBrickCell x kBrickCell cell (one wave per
+    // cell, no overlap: a brick's pixel box queries every cell it touches)
+    const int c = (int)(bid - thr_blocks - coarse_blocks) * 4 + (int)(threadIdx.x >> 6);
+    if (c >= ccw * cch)
+      return;
+    const int cx = c % ccw, cy = c / ccw;
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    for (int i = lane; i < kBrickCell * kBrickCell; i += 64)
+    {
+      const int x = kBrickCell * cx + i % kBrickCell, y = kBrickCell * cy + i / kBrickCell;
+      if (x < cols && y < rows)
+      {
+        const uint32_t bits = *(const uint16_t*)(dists + (size_t)y * dists_pitch + (size_t)x * 2u);
+        f32x2 ab = band_thresholds(half_bits_to_float(bits), trunc_hi);
+        if (ab.y >= 0.f)  // the word the kernel compares d2 with (see above): >= B2
+          ab.y = __uint_as_float(((__float_as_uint(ab.y) + 0xffffu) & 0xffff0000u) | bits);
+        lo = __builtin_fminf(lo, ab.x);
+        hi = __builtin_fmaxf(hi, ab.y);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+    {
+      lo = __builtin_fminf(lo, __shfl_xor(lo, off));
+      hi = __builtin_fmaxf(hi, __shfl_xor(hi, off));
+    }
+    if (lane == 0)
+    {
+      cellmin[c] = lo;
+      cellmax[c] = hi;
+    }
+    return;
+  }
   const int cell = (int)(bid - thr_blocks) * 4 + (int)(threadIdx.x >> 6);
   if (cell >= cw * ch)
     return;
-  const int lane = (int)(threadIdx.x & 63u);
   const int bx = cell % cw, by = cell / cw;
   const int w = 2 * bk;
   float m = __builtin_inff();
@@ -577,12 +614,15 @@ __device__ __forceinline__ void update(const IntegrateParams& p, const Pos<VX>& 
 
   vec_t out = buf;
   fuse_run<VX>(buf, out, hit, unit, tsdf, p.max_weight, max_w_hi);
-  buf_store<VX, NT>(out, rs, lanes(hit_any) ? voff : kNoAccess, soff);
+  // (an access that is switched off for the whole wave -- a layer past the chunk's end -- also gets a scalar
+  // offset inside the descriptor: voffset 2^31 is then out of range whether the hardware compares
+  // voffset >= num_records - soffset or voffset + soffset >= num_records)
+  buf_store<VX, NT>(out, rs, lanes(hit_any) ? voff : kNoAccess, live ? soff : 0u);
 
   // look-ahead: updates are coherent along z, so a lane that updated this layer will very likely
   // update the layer two steps on (this buffer's next use); fetch it now
   buf_valid = ahead_ok ? hit_any : 0;
-  buf = buf_load<VX, NT>(rs, lanes(buf_valid) ? voff : kNoAccess, soff + 2u * layer_bytes);
+  buf = buf_load<VX, NT>(rs, lanes(buf_valid) ? voff : kNoAccess, ahead_ok ? soff + 2u * layer_bytes : 0u);
 }
 
 // blockIdx.y -> z-chunk: in order, or 0, n - 1, 1, n - 2, ... (see integrate_kernel)
@@ -609,12 +649,202 @@ __device__ __forceinline__ bool lane_voxels(const IntegrateParams& p, uint32_t& 
   // the launcher only picks a tile that divides the layer: every lane owns voxels
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t lanes_x = 1u << p.tile_shift, rows_wave = 64u >> p.tile_shift;
-  const uint32_t blocks_per_row = (uint32_t)p.X / (lanes_x * VX);
-  const uint32_t bx = blockIdx.x % blocks_per_row, by = blockIdx.x / blocks_per_row;
-  x0 = (int)((bx * lanes_x + (lane & (lanes_x - 1u))) * VX);
-  y = (int)(by * 4u * rows_wave + wave * rows_wave + (lane >> p.tile_shift));
+  if (p.tile_side)
+  {
+    // the four waves side by side along x: the workgroup covers 4 * lanes_x * VX voxels of rows_wave rows, so
+    // each row is one long contiguous run (memory sees what the layer-order footprint gives it) while every
+    // wave's own patch stays compact (the brick test and the per-voxel path work wave by wave)
+    const uint32_t blocks_per_row = (uint32_t)p.X / (4u * lanes_x * VX);
+    const uint32_t bx = blockIdx.x % blocks_per_row, by = blockIdx.x / blocks_per_row;
+    x0 = (int)(((bx * 4u + wave) * lanes_x + (lane & (lanes_x - 1u))) * VX);
+    y = (int)(by * rows_wave + (lane >> p.tile_shift));
+  }
+  else
+  {
+    const uint32_t blocks_per_row = (uint32_t)p.X / (lanes_x * VX);
+    const uint32_t bx = blockIdx.x % blocks_per_row, by = blockIdx.x / blocks_per_row;
+    x0 = (int)((bx * lanes_x + (lane & (lanes_x - 1u))) * VX);
+    y = (int)(by * 4u * rows_wave + wave * rows_wave + (lane >> p.tile_shift));
+  }
   elem = (uint32_t)y * (uint32_t)p.X + (uint32_t)x0;
   return true;
+}
+
+// ---- brick test: settle a whole workgroup x z-chunk before it touches anything ------------------
+// A wave owns a brick of voxels: its x-y footprint in the layer times the layers [zs, ze) of its chunk.
+// The brick is convex, so in front of the camera its pixels lie in the bounding box of its 8 projected corners
+// and its squared distances between the distance to its camera-space bounding box and the farthest corner.
+// Three outcomes, each a sufficient condition for what the per-voxel path would decide voxel by voxel:
+//   dead   no voxel can take an update: the brick is behind the camera (tsdf_volume.cu:89), projects outside
+//          the image (:83), or lies behind the surface by more than the truncation distance at every pixel
+//          it can see -- min d2 > max over the box of the pixels' B2 word (:94; a pixel without a return has
+//          B2 = -1).  The wave exits: no replay, no memory access (and no LDS fill if no wave of the workgroup
+//          is mixed).
+//   front  every voxel takes the update with tsdf = 1: the box lies inside the image and max d2 <= min A2
+//          over it.  The wave streams the chunk: load, weight bump (or general fuse), store.
+//   mixed  anything else: the per-voxel path.
+// The positions the kernel works with are the reference's replayed fp32 sums, not the ideal affine images:
+// brick_eps bounds their distance per coordinate (host: (z1 + 32) * 2^-22 * P, P = largest |camera
+// coordinate| in the volume -- each of the <= z1 + 8 roundings is below 2^-24 * 2P) and every bound below is
+// widened by it; the pixel box by the matching projection error + 1/32 px for this routine's own roundings.
+enum BrickClass
+{
+  kBrickMixed = 0,
+  kBrickDead = 1,
+  kBrickFront = 2
+};
+
+template <int VX>
+__device__ __forceinline__ int classify_brick(const IntegrateParams& p, int zs, int ze)
+{
+  // voxel index ranges of this WAVE (see lane_voxels)
+  int xlo, xhi, ylo, yhi;
+  const uint32_t wave = threadIdx.x >> 6;
+  if (p.tile_shift >= 6)
+  {
+    const uint32_t e0 = (blockIdx.x * 4u + wave) * (64u * VX);
+    uint32_t e1 = e0 + (64u * VX - 1u);
+    if (e1 >= p.plane)
+      e1 = p.plane - 1u;  // (a wave that starts beyond the layer owns nothing: its class is never used)
+    ylo = (int)(e0 / (uint32_t)p.X);
+    yhi = (int)(e1 / (uint32_t)p.X);
+    xlo = ylo == yhi ? (int)(e0 - (uint32_t)ylo * (uint32_t)p.X) : 0;
+    xhi = ylo == yhi ? (int)(e1 - (uint32_t)yhi * (uint32_t)p.X) : p.X - 1;
+  }
+  else
+  {
+    const uint32_t lanes_x = 1u << p.tile_shift, rows_wave = 64u >> p.tile_shift;
+    if (p.tile_side)
+    {
+      const uint32_t blocks_per_row = (uint32_t)p.X / (4u * lanes_x * VX);
+      const uint32_t bx = blockIdx.x % blocks_per_row, by = blockIdx.x / blocks_per_row;
+      xlo = (int)((bx * 4u + wave) * lanes_x * VX);
+      ylo = (int)(by * rows_wave);
+    }
+    else
+    {
+      const uint32_t blocks_per_row = (uint32_t)p.X / (lanes_x * VX);
+      const uint32_t bx = blockIdx.x % blocks_per_row, by = blockIdx.x / blocks_per_row;
+      xlo = (int)(bx * lanes_x * VX);
+      ylo = (int)((by * 4u + wave) * rows_wave);
+    }
+    xhi = xlo + (int)(lanes_x * VX) - 1;
+    yhi = ylo + (int)rows_wave - 1;
+  }
+  // corner (lane & 7) of the brick in camera space (every lane group of 8 computes the same 8 corners)
+  const uint32_t lane = threadIdx.x & 63u;
+  const float vx = (float)((lane & 1u) ? xhi : xlo) * p.vsx;
+  const float vy = (float)((lane & 2u) ? yhi : ylo) * p.vsy;
+  const float vz = (float)((lane & 4u) ? ze - 1 : zs) * p.vsz;
+  const float cx = dot3(p.R[0], p.R[1], p.R[2], vx, vy, vz) + p.t[0];
+  const float cy = dot3(p.R[3], p.R[4], p.R[5], vx, vy, vz) + p.t[1];
+  const float cz = dot3(p.R[6], p.R[7], p.R[8], vx, vy, vz) + p.t[2];
+  const float e = p.brick_eps;
+  float xmin = cx, xmax = cx, ymin = cy, ymax = cy, zmin = cz, zmax = cz;
+  const float ax = __builtin_fabsf(cx) + e, ay = __builtin_fabsf(cy) + e, az = __builtin_fabsf(cz) + e;
+  float d2max = __builtin_fmaf(ax, ax, __builtin_fmaf(ay, ay, az * az));
+  // projection of the corner (only meaningful, and only used, when the whole brick has z > brick_zmin)
+  const float iz = 1.f / cz;
+  float umin = __builtin_fmaf(p.fx, cx * iz, p.cx), vmin = __builtin_fmaf(p.fy, cy * iz, p.cy);
+  float umax = umin, vmax = vmin;
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1)
+  {
+    xmin = __builtin_fminf(xmin, __shfl_xor(xmin, off));
+    xmax = __builtin_fmaxf(xmax, __shfl_xor(xmax, off));
+    ymin = __builtin_fminf(ymin, __shfl_xor(ymin, off));
+    ymax = __builtin_fmaxf(ymax, __shfl_xor(ymax, off));
+    zmin = __builtin_fminf(zmin, __shfl_xor(zmin, off));
+    zmax = __builtin_fmaxf(zmax, __shfl_xor(zmax, off));
+    umin = __builtin_fminf(umin, __shfl_xor(umin, off));
+    umax = __builtin_fmaxf(umax, __shfl_xor(umax, off));
+    vmin = __builtin_fminf(vmin, __shfl_xor(vmin, off));
+    vmax = __builtin_fmaxf(vmax, __shfl_xor(vmax, off));
+    d2max = __builtin_fmaxf(d2max, __shfl_xor(d2max, off));
+  }
+  xmin -= e, ymin -= e, zmin -= e, xmax += e, ymax += e, zmax += e;
+  int cls = kBrickMixed;
+  if (zmax <= 0.f)
+    cls = kBrickDead;  // every voxel has vc.z <= 0
+  else if (zmin >= p.brick_zmin)
+  {
+    const float xabs = __builtin_fmaxf(__builtin_fabsf(xmin), __builtin_fabsf(xmax));
+    const float yabs = __builtin_fmaxf(__builtin_fabsf(ymin), __builtin_fabsf(ymax));
+    const float rz = 1.f / (zmin - e);
+    const float du = __builtin_fmaf(p.fx * e * (1.f + xabs * rz), rz * 1.01f, 1.f / 32.f);
+    const float dv = __builtin_fmaf(p.fy * e * (1.f + yabs * rz), rz * 1.01f, 1.f / 32.f);
+    umin -= du, umax += du, vmin -= dv, vmax += dv;
+    const float fc = (float)p.cols, fr = (float)p.rows;
+    if (umax < 0.f || vmax < 0.f || umin >= fc || vmin >= fr)
+      cls = kBrickDead;  // every voxel projects outside the image
+    else
+    {
+      // cells the box touches, clipped to the image
+      const int px0 = (int)__builtin_fmaxf(__builtin_floorf(umin), 0.f), px1 = (int)__builtin_fminf(__builtin_floorf(umax), fc - 1.f);
+      const int py0 = (int)__builtin_fmaxf(__builtin_floorf(vmin), 0.f), py1 = (int)__builtin_fminf(__builtin_floorf(vmax), fr - 1.f);
+      const int cx0 = px0 / kBrickCell, cy0 = py0 / kBrickCell;
+      const int ncx = px1 / kBrickCell - cx0 + 1, ncy = py1 / kBrickCell - cy0 + 1;
+      const int n = ncx * ncy;
+      if (n <= 256)
+      {
+        float amin = __builtin_inff(), bmax = -__builtin_inff();
+        for (int i = (int)lane; i < n; i += 64)
+        {
+          const int yy = i / ncx, xx = i - yy * ncx;
+          const int idx = (cy0 + yy) * p.ccw + cx0 + xx;
+          amin = __builtin_fminf(amin, p.cellmin[idx]);
+          bmax = __builtin_fmaxf(bmax, p.cellmax[idx]);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+        {
+          amin = __builtin_fminf(amin, __shfl_xor(amin, off));
+          bmax = __builtin_fmaxf(bmax, __shfl_xor(bmax, off));
+        }
+        // squared distance from the camera to the brick's (widened) camera-space bounding box
+        const float mx = xmin > 0.f ? xmin : (xmax < 0.f ? -xmax : 0.f);
+        const float my = ymin > 0.f ? ymin : (ymax < 0.f ? -ymax : 0.f);
+        const float d2min = __builtin_fmaf(mx, mx, __builtin_fmaf(my, my, zmin * zmin)) * 0x1.ffep-1f;  // 1 - 2^-11
+        const bool inside = umin >= 0.5f && vmin >= 0.5f && umax < fc - 0.5f && vmax < fr - 0.5f;
+        if (d2min > bmax)
+          cls = kBrickDead;  // behind the surface (or no return) at every pixel the brick can see
+        else if (inside && d2max * 0x1.002p+0f <= amin)
+          cls = kBrickFront;  // in front of the surface by more than the truncation distance, everywhere
+      }
+    }
+  }
+  return __builtin_amdgcn_readfirstlane(cls);
+}
+
+// A "front" brick: every voxel of the chunk takes the measurement 1.0.  Plain streaming: two layers in flight.
+template <int VX, bool NT>
+__device__ __forceinline__ void walk_front(const IntegrateParams& p, rsrc_t rs, uint32_t voff, uint32_t layer_bytes,
+                                           int layers, mask_t active, uint32_t max_w_hi)
+{
+  typedef typename Vec<VX>::type vec_t;
+  mask_t hit[VX], unit[VX];
+  float tsdf[VX];
+#pragma unroll
+  for (int v = 0; v < VX; ++v)
+  {
+    hit[v] = unit[v] = active;
+    tsdf[v] = 1.f;
+  }
+  vec_t b0 = buf_load<VX, NT>(rs, voff, 0u);
+  vec_t b1 = buf_load<VX, NT>(rs, layers > 1 ? voff : kNoAccess, layers > 1 ? layer_bytes : 0u);
+  uint32_t soff = 0;
+  for (int i = 0; i < layers; i += 2, soff += 2u * layer_bytes)
+  {
+    vec_t o0 = b0;
+    fuse_run<VX>(b0, o0, hit, unit, tsdf, p.max_weight, max_w_hi);
+    buf_store<VX, NT>(o0, rs, voff, soff);
+    const bool a2 = i + 2 < layers, a1 = i + 1 < layers, a3 = i + 3 < layers;
+    b0 = buf_load<VX, NT>(rs, a2 ? voff : kNoAccess, a2 ? soff + 2u * layer_bytes : 0u);
+    vec_t o1 = b1;
+    fuse_run<VX>(b1, o1, hit, unit, tsdf, p.max_weight, max_w_hi);
+    buf_store<VX, NT>(o1, rs, a1 ? voff : kNoAccess, a1 ? soff + layer_bytes : 0u);
+    b1 = buf_load<VX, NT>(rs, a3 ? voff : kNoAccess, a3 ? soff + 3u * layer_bytes : 0u);
+  }
 }
 
 // VX voxels per lane along x.  The z loop is software-pipelined two layers deep with two register
@@ -626,21 +856,6 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
   typedef typename Vec<VX>::type vec_t;
   extern __shared__ __attribute__((aligned(16))) float coarse_lds[];
 
-  // the coarse threshold image (a few KiB) is read once per workgroup into LDS
-  if (VX == 4 && p.grp_enable)
-  {
-    const int n = p.cw * p.ch;
-    for (int i = (int)threadIdx.x; i < n; i += 256)
-      coarse_lds[i] = p.coarse[i];
-    __syncthreads();
-  }
-
-  uint32_t elem;  // x + y*X of the lane's first voxel; X % VX == 0 so no row straddle
-  int x0, y;
-  if (!lane_voxels<VX>(p, elem, x0, y))
-    return;
-  const mask_t active = ballot(true);
-
   // Chunks are handed out shallow and deep in turn (0, n-1, 1, n-2, ...).  In plain ascending order the deep
   // chunks -- the longest replays, and on a scene seen from the front the ones that hold the surface -- all
   // come last and make the tail; deepest first, every wave of a SIMD replays at once with no traffic to
@@ -650,6 +865,44 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
   // at 1024^3: 0.201 ms in order, 0.216 alternating), and so do the 4 MiB layers of wide slabs (rank 0: 0.196 / 0.206).
   const int zs = p.z0 + chunk_of_block((int)blockIdx.y, (int)gridDim.y, p.chunk_alt) * p.z_chunk;
   const int ze = min(zs + p.z_chunk, p.z1);
+
+  // each wave's brick first: most of a real frame's bricks end here.  The coarse threshold image (a few KiB,
+  // read once per workgroup into LDS) is only needed by mixed bricks; the waves agree on it through LDS.
+  __shared__ int wave_class[4];
+  const int brick = p.brick_enable ? classify_brick<VX>(p, zs, ze) : kBrickMixed;
+  bool fill = VX == 4 && p.grp_enable;
+  if (p.brick_enable)
+  {
+    if ((threadIdx.x & 63u) == 0)
+      wave_class[threadIdx.x >> 6] = brick;
+    __syncthreads();
+    fill = fill && (wave_class[0] == kBrickMixed || wave_class[1] == kBrickMixed || wave_class[2] == kBrickMixed ||
+                    wave_class[3] == kBrickMixed);
+  }
+  if (fill)
+  {
+    const int n = p.cw * p.ch;
+    for (int i = (int)threadIdx.x; i < n; i += 256)
+      coarse_lds[i] = p.coarse[i];
+    __syncthreads();
+  }
+  if (brick == kBrickDead)
+    return;
+
+  uint32_t elem;  // x + y*X of the lane's first voxel; X % VX == 0 so no row straddle
+  int x0, y;
+  if (!lane_voxels<VX>(p, elem, x0, y))
+    return;
+  const mask_t active = ballot(true);
+
+  if (brick == kBrickFront)
+  {
+    const uint32_t lb = p.plane * 4u;
+    const rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(p.vol + (size_t)(zs - p.z0) * p.plane, 0,
+                                                         (uint32_t)(ze - zs) * lb, 0x00020000);
+    walk_front<VX, NT>(p, rsf, elem * 4u, lb, ze - zs, active, ((uint32_t)p.max_weight << 16) | 0xffffu);
+    return;
+  }
 
   // :69
   const float zsx = p.R[2] * p.vsz, zsy = p.R[5] * p.vsz, zsz = p.R[8] * p.vsz;
@@ -712,7 +965,7 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
   stage1<VX>(p, A, PA, coarse_lds, active, fx2, fy2, cx2, cy2);
   __builtin_amdgcn_sched_barrier(0);
   buf_store<VX, NT>(bufA, rs, kNoAccess, 0u);
-  vec_t bufB = buf_load<VX, NT>(rs, validB ? voff : kNoAccess, layer_bytes);
+  vec_t bufB = buf_load<VX, NT>(rs, validB ? voff : kNoAccess, validB ? layer_bytes : 0u);
   __builtin_amdgcn_sched_barrier(0);
   uint32_t soff = 0;
   for (int z = zs; z < ze; z += 2, soff += 2u * layer_bytes)
@@ -755,7 +1008,8 @@ static int launch_variant(yakhip_ctx* ctx, const IntegrateParams& p, dim3 grid, 
 constexpr size_t kStaticMaxPixels = YAKHIP_STATIC_MAX_PIXELS;    // image of the frame
 constexpr size_t kStaticMaxColumns = YAKHIP_STATIC_MAX_COLUMNS;  // X * Y up to which a deep slab gets checkpoints
 constexpr size_t kStaticCoarseCap = 32768;
-constexpr size_t kStaticFrameBytes = kStaticMaxPixels * sizeof(f32x2) + kStaticCoarseCap;
+constexpr size_t kStaticCellCap = 1u << 20;  // both brick-test planes (8 B per 16 x 16 pixel cell)
+constexpr size_t kStaticFrameBytes = kStaticMaxPixels * sizeof(f32x2) + kStaticCoarseCap + kStaticCellCap;
 constexpr size_t kStaticCkptBytes = kStaticMaxColumns * 3u * sizeof(float);
 static __device__ __align__(256) unsigned char scratch[kStaticFrameBytes + kStaticCkptBytes];
 
@@ -814,12 +1068,16 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
   p.ch = (p.rows + bk - 1) / bk;
   const size_t thr_bytes = (size_t)p.rows * (size_t)p.cols * sizeof(f32x2);
   const size_t coarse_bytes = (size_t)p.cw * p.ch * sizeof(float);
-  const size_t slot_bytes = (thr_bytes + coarse_bytes + 255u) & ~(size_t)255u;
+  p.ccw = (p.cols + kBrickCell - 1) / kBrickCell;
+  p.cch = (p.rows + kBrickCell - 1) / kBrickCell;
+  const size_t cell_bytes = (size_t)p.ccw * p.cch * sizeof(float);  // per plane
+  const size_t slot_bytes = (thr_bytes + coarse_bytes + 2u * cell_bytes + 255u) & ~(size_t)255u;
   if (use_static)
   {
     if (!ctx->static_scratch)
       return fail(YAKHIP_EINVAL, "integrate_static: the context holds no address of the static scratch");
-    if ((size_t)p.rows * (size_t)p.cols > kStaticMaxPixels || coarse_bytes > kStaticCoarseCap)
+    if ((size_t)p.rows * (size_t)p.cols > kStaticMaxPixels || coarse_bytes > kStaticCoarseCap ||
+        2u * cell_bytes > kStaticCellCap)
       return fail(YAKHIP_ERANGE, "integrate_static: a %d x %d image exceeds the static scratch (at most %zu pixels)",
                   p.cols, p.rows, kStaticMaxPixels);
   }
@@ -840,6 +1098,8 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
   char* base = use_static ? (char*)ctx->static_scratch : (char*)ctx->thr + slot_bytes * (size_t)slot;
   p.thr = (const f32x2*)base;
   p.coarse = (const float*)(base + thr_bytes);
+  p.cellmin = (const float*)(base + thr_bytes + coarse_bytes);
+  p.cellmax = (const float*)(base + thr_bytes + coarse_bytes + cell_bytes);
   {
     const int rc = prepare_checkpoint(ctx, p, slot, slots, use_static);
     if (rc != 0)
@@ -848,9 +1108,12 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
     const uint32_t thr_blocks = thr_blocks_x * (uint32_t)p.rows;
     const uint32_t cell_blocks = (uint32_t)((p.cw * p.ch + 3) / 4);
     const uint32_t ckpt_blocks = p.ckpt ? (p.plane + 255u) / 256u : 0u;
-    hipLaunchKernelGGL(prepass_kernel, dim3(thr_blocks + cell_blocks + ckpt_blocks), dim3(256), 0, ctx->stream, p.dists,
-                       p.dists_pitch, p.rows, p.cols, p.trunc_hi, (f32x2*)base, (float*)(base + thr_bytes), p.cw, p.ch,
-                       bk, thr_blocks_x, thr_blocks, ckpt_blocks, p, const_cast<float*>(p.ckpt));
+    const uint32_t brick_blocks = (uint32_t)((p.ccw * p.cch + 3) / 4);
+    hipLaunchKernelGGL(prepass_kernel, dim3(thr_blocks + cell_blocks + brick_blocks + ckpt_blocks), dim3(256), 0,
+                       ctx->stream, p.dists, p.dists_pitch, p.rows, p.cols, p.trunc_hi, (f32x2*)base,
+                       (float*)(base + thr_bytes), p.cw, p.ch, bk, thr_blocks_x, thr_blocks, ckpt_blocks, p,
+                       const_cast<float*>(p.ckpt), const_cast<float*>(p.cellmin), const_cast<float*>(p.cellmax), p.ccw,
+                       p.cch, cell_blocks);
     YAKHIP_TRY(hipGetLastError());
   }
 
@@ -879,6 +1142,11 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
     // the test assumes an ordinary pinhole (positive focal lengths, image below 32k px) and finite pose
     p.grp_enable = ctx->group_test && p.fx > 0.f && p.fy > 0.f && p.cols < 32768 && p.rows < 32768 &&
                    std::isfinite(P) && std::isfinite(f) && coarse_bytes <= coarse_cap_bytes;
+    // brick test (classify_brick): position slack and the nearest depth it is trusted at
+    p.brick_eps = (float)(p.z1 + 32) * 0x1p-22f * P;
+    p.brick_zmin = fmaxf(p.grp_zmin, 8.f * p.brick_eps);
+    p.brick_enable = ctx->brick_test && p.fx > 0.f && p.fy > 0.f && p.cols < 32768 && p.rows < 32768 &&
+                     std::isfinite(P) && std::isfinite(f) && std::isfinite(p.cx) && std::isfinite(p.cy);
   }
   return 0;
 }
@@ -932,10 +1200,13 @@ static int choose_chunk(const yakhip_ctx* ctx, const IntegrateParams& p, uint32_
 // Largest compact tile (see lane_voxels) that divides the layer exactly; 6 = plain layer order.
 static int choose_tile(const yakhip_ctx* ctx, const IntegrateParams& p, int vx)
 {
-  int shift = ctx->tile_shift > 0 ? ctx->tile_shift : kDefaultTileShift;
+  // with the brick test a compact footprint (32 x 32 voxels for four voxels per lane) makes bricks that are
+  // small in every direction: their pixel boxes are small and most of them are settled whole
+  int shift = ctx->tile_shift > 0 ? ctx->tile_shift : (p.brick_enable ? 4 : kDefaultTileShift);
   for (; shift < 6; ++shift)
   {
-    const uint32_t tile_x = (1u << shift) * (uint32_t)vx, tile_y = 4u * (64u >> shift);
+    const uint32_t tile_x = (p.tile_side ? 4u : 1u) * (1u << shift) * (uint32_t)vx;
+    const uint32_t tile_y = (p.tile_side ? 1u : 4u) * (64u >> shift);
     if ((uint32_t)p.X % tile_x == 0 && (uint32_t)p.Y % tile_y == 0)
       break;
   }
@@ -962,6 +1233,7 @@ int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in, bool use_stat
 
   const uint32_t groups = p.plane / (uint32_t)vx;
   const uint32_t blocks_x = (groups + 255u) / 256u;
+  p.tile_side = ctx->tile_side;
   p.tile_shift = choose_tile(ctx, p, vx);
   int chunk = 0;
   uint32_t nchunks = 0;
@@ -1121,7 +1393,7 @@ __global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchPara
     buf_store<VX, NT>(out, rs, lanes(any) ? voff : kNoAccess, soff);
     // look-ahead: a lane that updated this layer very likely updates the next one
     have = z + 1 < ze ? any : 0;
-    cur = buf_load<VX, NT>(rs, lanes(have) ? voff : kNoAccess, soff + layer_bytes);
+    cur = buf_load<VX, NT>(rs, lanes(have) ? voff : kNoAccess, z + 1 < ze ? soff + layer_bytes : 0u);
   }
 }
 
@@ -1185,11 +1457,13 @@ int launch_integrate_batch(yakhip_ctx* ctx, const IntegrateParams* frames, int n
     int rc = choose_chunk(ctx, bp.f[0], blocks_x, 1024u, 48, &chunk, &nchunks);
     if (rc != 0)
       return rc;
+    bp.f[0].tile_side = ctx->tile_side;
     const int tile = choose_tile(ctx, bp.f[0], 4);
     for (int i = 0; i < kBatchMax; ++i)
     {
       bp.f[i].z_chunk = chunk;
       bp.f[i].tile_shift = tile;
+      bp.f[i].tile_side = ctx->tile_side;
       bp.f[i].chunk_alt = !bp.f[0].ckpt && bp.f[0].z0 == 0 && (uint64_t)bp.f[0].plane * 4u < (4ull << 20);
     }
     const dim3 grid(blocks_x, nchunks);

@@ -19,8 +19,10 @@ struct yakhip_ctx
   int force_vx;        // 0 = widest the layout allows; 1/2/4 caps the voxels per lane
   int zu;              // (unused; kept for option compatibility)
   int group_test;      // coarse group test on (default) / off
+  int brick_test;      // classify whole bricks (dead / front / mixed) before walking them (default) / off
   int checkpoint;      // deep slabs start from closed-form column positions (default) / replay from layer 0
   int tile_shift;      // 0 = default wave footprint, else 3..6 (tuning)
+  int tile_side;       // the four waves of a workgroup lie side by side along x (default) / stacked in y
   int mc_z_chunk;      // 0 = default cube layers per marching-cubes tile (tuning)
   void* thr;           // scratch: per-pixel band thresholds of the frame being integrated
   size_t thr_bytes;
@@ -71,6 +73,12 @@ struct IntegrateParams
   const f32x2* thr;      // per-pixel {A2, B2} band thresholds, dense rows x cols
   const float* coarse;   // coarse minima of A2 (group test), cw x ch cells
   const float* ckpt;     // nullptr, or camera-space x | y | z of every column at layer z0 (3 planes of X*Y floats)
+  const float* cellmin;  // brick test: min of A2 / max of the B2 word over each 16 x 16 pixel cell, ccw x cch cells
+  const float* cellmax;
+  int ccw, cch;
+  int brick_enable;      // classify each workgroup's brick (x-y tile times z-chunk) before walking it
+  float brick_eps;       // bound on |replayed fp32 position - ideal position| per camera coordinate (metres)
+  float brick_zmin;      // bricks nearer than this (camera z) are not classified
   int cw, ch;
   int grp_enable;
   float grp_margin, grp_cols_hi, grp_rows_hi, grp_span, grp_inv_bk, grp_bias, grp_zmin;
@@ -81,6 +89,7 @@ struct IntegrateParams
   int z_chunk;           // layers walked by one workgroup (grid.y index)
   int chunk_alt;         // 1: chunks are handed out shallow and deep in turn (integrate.hip chunk_of_block)
   int tile_shift;        // log2 of the lanes a wave lays along x (6 = layer order); integrate.hip lane_voxels()
+  int tile_side;         // waves of a workgroup side by side along x (1) or stacked in y (0)
   uint32_t plane;        // X * Y
   float vsx, vsy, vsz;
   float trunc, trunc_inv;
