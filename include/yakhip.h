@@ -86,7 +86,8 @@ const char* yakhip_last_error(void);
  * whole workgroup bricks that cannot update, or update everywhere with tsdf 1, are settled before they are walked),
  * "checkpoint" (0/1: slabs with z0 >= 64 start from column positions computed in closed form instead of
  * replaying z0 additions per column), "tile" (0 or 3..6: wave footprint in the layer), "tile_side" (0/1: a workgroup's waves stacked in y / side by side in x), "mc_z_chunk"
- * (marching-cubes tile depth, 0 = auto), "kernel_timing" (0/1, see yakhip_ctx_kernel_time), "zu" (ignored).
+ * (marching-cubes tile depth, 0 = auto), "kernel_timing" (0/1, see yakhip_ctx_kernel_time), "brick_stats" (0/1, see
+ * yakhip_ctx_brick_stats), "zu" (ignored).
  * Unknown key or value -> YAKHIP_EINVAL. */
 int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value);
 /* Measurement aid with no counterpart in the reference (its only timers are the never-invoked
@@ -100,6 +101,11 @@ int yakhip_ctx_kernel_time(yakhip_ctx* ctx, double* total_ms, int* launches);
  * this one's start, for the first min(*launches, capacity) launches; *launches = how many were bracketed.
  * Restarts the accumulation.  bench.py prints this series so that slow launches can be told from the mean. */
 int yakhip_ctx_kernel_times(yakhip_ctx* ctx, float* ms_out, float* start_ms_out, int capacity, int* launches);
+/* Measurement aid, no counterpart in the reference: after yakhip_ctx_set_option(ctx, "brick_stats", 1) the
+ * single-frame integrate kernel counts how its whole-brick test classified the wave bricks it looked at;
+ * this call waits, returns counts = {dead (no voxel can update: skipped), front (every voxel updates with
+ * tsdf 1: streamed), mixed (walked voxel by voxel)} since the last call and restarts the count. */
+int yakhip_ctx_brick_stats(yakhip_ctx* ctx, unsigned long long counts[3]);
 /* Device self-test with no counterpart in the reference: the integrate kernel replaces IEEE '/' by a
  * v_rcp_f32 + Newton + Markstein sequence; this checks on the GPU at hand that (a) the refined
  * reciprocal is the correctly rounded 1/d for all 2^23 mantissas at 8 exponents and (b) the quotient

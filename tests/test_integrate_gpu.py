@@ -417,3 +417,96 @@ def test_integrate_wave_footprint_does_not_change_results(gpu_ctx, tile):
         assert np.array_equal(got, want)
     with pytest.raises(capi.YakHipError):
         gpu_ctx.set_option("tile", 2)
+
+
+# ---------------------------------------------------------------------------- whole-brick test
+def _punch_holes(depth, rng, n):
+    """Blocks of pixels without a return (Dp == 0, tsdf_volume.cu:89): aligned to the brick test's 16-pixel
+    cells and not, from a few pixels to a quarter of the image."""
+    rows, cols = depth.shape
+    for k in range(n):
+        h, w = int(rng.integers(3, rows // 2)), int(rng.integers(3, cols // 2))
+        y, x = int(rng.integers(0, rows - h)), int(rng.integers(0, cols - w))
+        if k % 2 == 0:
+            y, x, h, w = y & ~15, x & ~15, (h + 15) & ~15, (w + 15) & ~15
+        depth[y:y + h, x:x + w] = 0
+    return depth
+
+
+@pytest.mark.parametrize("seed", range(9))
+def test_integrate_brick_test_borders_near_plane_and_holes(gpu_ctx, seed):
+    """The whole-brick test (integrate.hip, classify_brick) must only ever skip bricks that cannot update and
+    only stream bricks that update everywhere with tsdf 1.  Cameras whose frustum cuts through the volume
+    (bricks straddle the image borders), cameras inside it (bricks straddle the camera plane, vc.z <= 0 on
+    one side), images with holes; every wave footprint, short chunks so that a small volume has many bricks.
+    Word for word against the oracle, with the test on and off."""
+    rng = np.random.default_rng(7000 + seed)
+    rows, cols = [(480, 640), (240, 320), (131, 97)][seed % 3]
+    f = cols * rng.uniform(0.8, 2.5)  # up to a narrow field of view: most of the volume is outside the image
+    intr = (float(f), float(f * rng.uniform(0.95, 1.05)), float(cols / 2 + rng.uniform(-30, 30)),
+            float(rows / 2 + rng.uniform(-30, 30)))
+    dims = [(256, 64, 96), (128, 96, 80), (512, 32, 48)][seed % 3]
+    _, vs, tr = synth.volume_geometry(dims)
+    nvox = int(np.prod(dims))
+    want = np.zeros(nvox, dtype=np.uint32)
+    frames = []
+    for frame in range(2):
+        R_c2v, eye = _random_pose(rng, inside=(seed % 2 == 1))
+        spheres = [(rng.uniform(0.5, 2.5, 3), float(rng.uniform(0.2, 0.9))) for _ in range(2)]
+        planes = [((0, 0, float(rng.uniform(1.5, 3.5))), (0, 0, 1)), ((0, float(rng.uniform(1.0, 3.2)), 0), (0, 1, 0))]
+        depth = synth.render_depth(R_c2v, eye, planes=planes, spheres=spheres, intr=intr, rows=rows, cols=cols,
+                                   noise_mm=1.0, seed=seed * 10 + frame)
+        depth = _punch_holes(depth, rng, 6)
+        R, t = synth.vol2cam(R_c2v, eye)
+        dists = oracle.compute_dists(depth, intr)
+        oracle.integrate(want, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, intr, nthreads=oracle.max_threads())
+        frames.append((dists, R, t))
+    assert np.count_nonzero(want) > 0
+
+    def run():
+        got = np.zeros(nvox, dtype=np.uint32)
+        for dists, R, t in frames:
+            got = gpu_integrate(gpu_ctx, got, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, intr)
+        return got
+
+    stats = {}
+    try:
+        gpu_ctx.set_option("brick_stats", 1)
+        for z_chunk, tile, side in [(16, 0, 1), (8, 3, 1), (16, 5, 1), (16, 3, 0), (0, 6, 1)]:
+            gpu_ctx.set_option("z_chunk", z_chunk)
+            gpu_ctx.set_option("tile", tile)
+            gpu_ctx.set_option("tile_side", side)
+            assert_parity(run(), want)
+            s = gpu_ctx.brick_stats()
+            for k in s:
+                stats[k] = stats.get(k, 0) + s[k]
+        gpu_ctx.set_option("brick_test", 0)
+        assert_parity(run(), want)
+        assert sum(gpu_ctx.brick_stats().values()) > 0  # (all counted as mixed)
+    finally:
+        for key, v in [("brick_test", 1), ("brick_stats", 0), ("z_chunk", 0), ("tile", 0), ("tile_side", 1)]:
+            gpu_ctx.set_option(key, v)
+    assert stats["dead"] > 0 and stats["mixed"] > 0, stats  # the cases do reach the outcomes they are for
+
+
+def test_integrate_brick_test_classes_on_known_scenes(gpu_ctx):
+    """S0 (every voxel in view, in front of the wall): every brick is 'front' and the volume is (1.0, k) after
+    k frames.  A frame without any return: every brick is 'dead' and nothing is written."""
+    n = 128
+    dims, vs, tr = synth.volume_geometry(n)
+    depth, R, t = synth.scene_s0()
+    dists = oracle.compute_dists(depth, synth.INTR)
+    gpu_ctx.set_option("brick_stats", 1)
+    try:
+        got = gpu_integrate(gpu_ctx, np.zeros(n ** 3, dtype=np.uint32), dims, vs, tr, synth.MAX_WEIGHT, dists, R, t,
+                            synth.INTR, frames=3)
+        s0 = gpu_ctx.brick_stats()
+        none = gpu_integrate(gpu_ctx, np.zeros(n ** 3, dtype=np.uint32), dims, vs, tr, synth.MAX_WEIGHT,
+                             np.zeros_like(dists), R, t, synth.INTR)
+        s1 = gpu_ctx.brick_stats()
+    finally:
+        gpu_ctx.set_option("brick_stats", 0)
+    assert np.all(got == ((3 << 16) | 0x3C00))
+    assert s0["front"] > 0 and s0["dead"] == 0 and s0["mixed"] == 0, s0
+    assert not none.any()
+    assert s1["dead"] > 0 and s1["front"] == 0 and s1["mixed"] == 0, s1

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libyakhip.so")
 EXPORTS = [
     "yakhip_ctx_create", "yakhip_ctx_destroy", "yakhip_ctx_set_stream", "yakhip_ctx_use_own_stream", "yakhip_ctx_synchronize",
     "yakhip_device_count", "yakhip_device_name", "yakhip_last_error", "yakhip_ctx_set_option",
-    "yakhip_ctx_kernel_time", "yakhip_ctx_kernel_times", "yakhip_selftest_division",
+    "yakhip_ctx_kernel_time", "yakhip_ctx_kernel_times", "yakhip_ctx_brick_stats", "yakhip_selftest_division",
     "yakhip_malloc", "yakhip_malloc_pitch", "yakhip_free", "yakhip_upload", "yakhip_download",
     "yakhip_upload_2d", "yakhip_download_2d", "yakhip_copy", "yakhip_copy_2d",
     "yakhip_clear_volume", "yakhip_compute_dists", "yakhip_integrate", "yakhip_integrate_static",
@@ -93,6 +93,7 @@ def load():
         "yakhip_ctx_set_option": [vp, C.c_char_p, i],
         "yakhip_ctx_kernel_time": [vp, C.POINTER(C.c_double), C.POINTER(i)],
         "yakhip_ctx_kernel_times": [vp, fp, fp, i, C.POINTER(i)],
+        "yakhip_ctx_brick_stats": [vp, C.POINTER(C.c_ulonglong)],
         "yakhip_selftest_division": [vp, C.POINTER(C.c_ulonglong)],
         "yakhip_malloc": [vp, C.POINTER(vp), sz],
         "yakhip_malloc_pitch": [vp, C.POINTER(vp), C.POINTER(sz), sz, sz],
@@ -204,6 +205,12 @@ class Context:
         _chk(load().yakhip_ctx_kernel_times(self._h, ms, st, capacity, C.byref(n)))
         k = min(n.value, capacity)
         return list(ms[:k]), list(st[:k])
+
+    def brick_stats(self):
+        """{dead, front, mixed} wave bricks of the integrate launches since the last call ("brick_stats" option)."""
+        out = (C.c_ulonglong * 3)()
+        _chk(load().yakhip_ctx_brick_stats(self._h, out))
+        return {"dead": int(out[0]), "front": int(out[1]), "mixed": int(out[2])}
 
     def selftest_division(self):
         out = (C.c_ulonglong * 4)()

@@ -133,6 +133,7 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->ckpt = nullptr;
   ctx->ckpt_bytes = 0;
   ctx->static_scratch = nullptr;
+  ctx->brick_stats = nullptr;
   ctx->icp_scratch = nullptr;
   ctx->icp_scratch_bytes = 0;
   ctx->icp_pinned = nullptr;
@@ -174,6 +175,8 @@ int yakhip_ctx_destroy(yakhip_ctx* ctx)
       (void)hipFree(ctx->thr);
     if (ctx->ckpt)
       (void)hipFree(ctx->ckpt);
+    if (ctx->brick_stats)
+      (void)hipFree(ctx->brick_stats);
     if (ctx->icp_scratch)
       (void)hipFree(ctx->icp_scratch);
     if (ctx->icp_pinned)
@@ -265,6 +268,24 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
     ctx->brick_test = value != 0;
     return 0;
   }
+  if (strcmp(key, "brick_stats") == 0)
+  {
+    int rc = enter(ctx);
+    if (rc != 0)
+      return rc;
+    if (value && !ctx->brick_stats)
+    {
+      YAKHIP_TRY(hipMalloc((void**)&ctx->brick_stats, 4 * sizeof(uint32_t)));
+      YAKHIP_TRY(hipMemsetAsync(ctx->brick_stats, 0, 4 * sizeof(uint32_t), ctx->stream));
+    }
+    else if (!value && ctx->brick_stats)
+    {
+      YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
+      YAKHIP_TRY(hipFree(ctx->brick_stats));
+      ctx->brick_stats = nullptr;
+    }
+    return 0;
+  }
   if (strcmp(key, "checkpoint") == 0)
   {
     ctx->checkpoint = value != 0;
@@ -338,6 +359,25 @@ int yakhip_ctx_kernel_times(yakhip_ctx* ctx, float* ms_out, float* start_ms_out,
   }
   *launches = (int)ctx->timing_used;
   ctx->timing_used = 0;
+  return 0;
+}
+
+int yakhip_ctx_brick_stats(yakhip_ctx* ctx, unsigned long long counts[3])
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!counts)
+    return fail(YAKHIP_EINVAL, "brick_stats: null out pointer");
+  if (!ctx->brick_stats)
+    return fail(YAKHIP_EINVAL, "brick_stats: switch the \"brick_stats\" option on first");
+  uint32_t host[4] = { 0, 0, 0, 0 };
+  YAKHIP_TRY(hipMemcpyAsync(host, ctx->brick_stats, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+  YAKHIP_TRY(hipMemsetAsync(ctx->brick_stats, 0, sizeof(host), ctx->stream));
+  YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
+  counts[0] = host[1];  // dead
+  counts[1] = host[2];  // front
+  counts[2] = host[0];  // mixed
   return 0;
 }
 

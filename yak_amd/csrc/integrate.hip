@@ -871,6 +871,8 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
   __shared__ int wave_class[4];
   const int brick = p.brick_enable ? classify_brick<VX>(p, zs, ze) : kBrickMixed;
   bool fill = VX == 4 && p.grp_enable;
+  if (p.brick_stats && (threadIdx.x & 63u) == 0)  // measurement aid, off by default
+    atomicAdd(&p.brick_stats[brick], 1u);
   if (p.brick_enable)
   {
     if ((threadIdx.x & 63u) == 0)
@@ -1145,6 +1147,7 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
     // brick test (classify_brick): position slack and the nearest depth it is trusted at
     p.brick_eps = (float)(p.z1 + 32) * 0x1p-22f * P;
     p.brick_zmin = fmaxf(p.grp_zmin, 8.f * p.brick_eps);
+    p.brick_stats = use_static ? nullptr : ctx->brick_stats;
     p.brick_enable = ctx->brick_test && p.fx > 0.f && p.fy > 0.f && p.cols < 32768 && p.rows < 32768 &&
                      std::isfinite(P) && std::isfinite(f) && std::isfinite(p.cx) && std::isfinite(p.cy);
   }
@@ -1290,7 +1293,31 @@ __global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchPara
   const IntegrateParams& p = bp.f[0];
 
   const int cells = p.cw * p.ch;  // the same for every frame: same image size, same cell size
-  if (p.grp_enable)
+  const int zs = p.z0 + chunk_of_block((int)blockIdx.y, (int)gridDim.y, p.chunk_alt) * p.z_chunk;  // as the single-frame kernel
+  const int ze = min(zs + p.z_chunk, p.z1);
+
+  // the wave's brick against every frame (classify_brick): a frame that cannot touch it is skipped for the
+  // whole chunk, one that updates all of it with tsdf 1 needs no projection; only mixed frames are walked
+  // voxel by voxel (and only they need positions, the replay and the coarse minima in LDS)
+  __shared__ int wave_mixed[4];
+  int cls[K];
+  bool any_mixed = false, all_dead = true;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+  {
+    cls[k] = p.brick_enable ? classify_brick<VX>(bp.f[k], zs, ze) : kBrickMixed;
+    any_mixed = any_mixed || cls[k] == kBrickMixed;
+    all_dead = all_dead && cls[k] == kBrickDead;
+  }
+  bool fill = p.grp_enable;
+  if (p.brick_enable)
+  {
+    if ((threadIdx.x & 63u) == 0)
+      wave_mixed[threadIdx.x >> 6] = any_mixed;
+    __syncthreads();
+    fill = fill && (wave_mixed[0] || wave_mixed[1] || wave_mixed[2] || wave_mixed[3]);
+  }
+  if (fill)
   {
 #pragma unroll
     for (int k = 0; k < K; ++k)
@@ -1298,20 +1325,22 @@ __global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchPara
         coarse_lds[k * cells + i] = bp.f[k].coarse[i];
     __syncthreads();
   }
+  if (all_dead)
+    return;
 
   uint32_t elem;  // x + y*X of the lane's first voxel; X % VX == 0 so no row straddle
   int x0, y;
   if (!lane_voxels<VX>(p, elem, x0, y))
     return;
   const mask_t active = ballot(true);
-  const int zs = p.z0 + chunk_of_block((int)blockIdx.y, (int)gridDim.y, p.chunk_alt) * p.z_chunk;  // as the single-frame kernel
-  const int ze = min(zs + p.z_chunk, p.z1);
 
   Pos<VX> pos[K];
   const float vxy = (float)y * p.vsy;
 #pragma unroll
   for (int k = 0; k < K; ++k)
   {
+    if (cls[k] != kBrickMixed)  // wave-uniform
+      continue;
     const IntegrateParams& f = bp.f[k];
 #pragma unroll
     for (int j = 0; j < Pos<VX>::NP; ++j)
@@ -1361,13 +1390,29 @@ __global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchPara
 #pragma unroll
     for (int k = 0; k < K; ++k)
     {
+      if (cls[k] == kBrickDead)  // wave-uniform
+        continue;
       const IntegrateParams& f = bp.f[k];
-      const f32x2 fx2 = { f.fx, f.fx }, fy2 = { f.fy, f.fy }, cx2 = { f.cx, f.cx }, cy2 = { f.cy, f.cy };
-      Probe<VX> pr;
-      stage1<VX>(f, pos[k], pr, coarse_lds + k * cells, active, fx2, fy2, cx2, cy2);
       mask_t hit[VX], unit[VX];
       float tsdf[VX];
-      settle<VX>(f, pos[k], pr, ~0ull, hit, unit, tsdf);
+      if (cls[k] == kBrickFront)
+      {
+#pragma unroll
+        for (int v = 0; v < VX; ++v)
+        {
+          hit[v] = unit[v] = active;
+          tsdf[v] = 1.f;
+        }
+      }
+      else
+      {
+        const f32x2 fx2 = { f.fx, f.fx }, fy2 = { f.fy, f.fy }, cx2 = { f.cx, f.cx }, cy2 = { f.cy, f.cy };
+        Probe<VX> pr;
+        stage1<VX>(f, pos[k], pr, coarse_lds + k * cells, active, fx2, fy2, cx2, cy2);
+        settle<VX>(f, pos[k], pr, ~0ull, hit, unit, tsdf);
+        const float zx = f.R[2] * p.vsz, zy = f.R[5] * p.vsz, zz = f.R[8] * p.vsz;
+        advance<VX>(pos[k], pos[k], f32x2{ zx, zx }, f32x2{ zy, zy }, f32x2{ zz, zz });
+      }
       const mask_t hk = hit[0] | hit[1] | hit[2] | hit[3];
       // only updated voxels are read (tsdf_volume.cu:98-100): fetch what the look-ahead did not bring.
       // A lane that needs it has not been touched by an earlier frame of this layer, so `out` is free.
@@ -1387,8 +1432,6 @@ __global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchPara
         fuse_run<VX>(prev, out, hit, unit, tsdf, p.max_weight, max_w_hi);
       }
       any |= hk;
-      const float zx = f.R[2] * p.vsz, zy = f.R[5] * p.vsz, zz = f.R[8] * p.vsz;
-      advance<VX>(pos[k], pos[k], f32x2{ zx, zx }, f32x2{ zy, zy }, f32x2{ zz, zz });
     }
     buf_store<VX, NT>(out, rs, lanes(any) ? voff : kNoAccess, soff);
     // look-ahead: a lane that updated this layer very likely updates the next one
@@ -1445,11 +1488,17 @@ int launch_integrate_batch(yakhip_ctx* ctx, const IntegrateParams* frames, int n
     for (int i = k; i < kBatchMax; ++i)
       bp.f[i] = bp.f[0];
     // the group test is per workgroup: on for the batch only if every frame allows it
-    bool grp = true;
+    bool grp = true, brick = true;
     for (int i = 0; i < k; ++i)
+    {
       grp = grp && bp.f[i].grp_enable;
+      brick = brick && bp.f[i].brick_enable;
+    }
     for (int i = 0; i < kBatchMax; ++i)
+    {
       bp.f[i].grp_enable = grp;
+      bp.f[i].brick_enable = brick;
+    }
     const uint32_t blocks_x = (p0.plane / 4u + 255u) / 256u;
     int chunk = 0;
     uint32_t nchunks = 0;

@@ -28,6 +28,7 @@ struct yakhip_ctx
   size_t thr_bytes;
   void* ckpt;          // scratch: column positions at layer z0 of a deep slab (integrate.hip, checkpoint_kernel)
   size_t ckpt_bytes;
+  uint32_t* brick_stats; // device counters {mixed, dead, front, -}, allocated by the "brick_stats" option
   void* static_scratch;  // this device's copy of integrate.hip's file-scope scratch array (yakhip_integrate_static)
   void* icp_scratch;   // ICP: workgroup partials + the reduced 33 values (device)
   size_t icp_scratch_bytes;
@@ -76,6 +77,7 @@ struct IntegrateParams
   const float* cellmin;  // brick test: min of A2 / max of the B2 word over each 16 x 16 pixel cell, ccw x cch cells
   const float* cellmax;
   int ccw, cch;
+  uint32_t* brick_stats; // nullptr, or counters {mixed, dead, front} of classified wave bricks ("brick_stats" option)
   int brick_enable;      // classify each workgroup's brick (x-y tile times z-chunk) before walking it
   float brick_eps;       // bound on |replayed fp32 position - ideal position| per camera coordinate (metres)
   float brick_zmin;      // bricks nearer than this (camera z) are not classified
