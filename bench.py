@@ -209,6 +209,58 @@ def kinfu_loop_row(ctx):
             "stage_ms": {k: round(v, 4) for k, v in r["stage_ms"].items()}}
 
 
+def orbit_views_row(ctx, torch, capi, synth):
+    """The hot path on surface-rich frames (the S0 wall is the kernel's best case): single-frame
+    integrate of 8 views of the S2 orbit into one 512^3 volume, kernel time per view from the library's event
+    pairs, voxels updated per view counted from the weights."""
+    n = VOXELS_PER_RANK_EDGE
+    rows, cols, intr = synth.ROWS, synth.COLS, synth.INTR
+    dims, vs, tr = synth.volume_geometry(n)
+    vol = torch.zeros(n ** 3, dtype=torch.int32, device="cuda")
+    desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT)
+    views, keep = [], []
+    for f in range(0, 300, 38):
+        depth, R, t = synth.scene_s2(f, noise_mm=1.0)
+        d = torch.from_numpy(depth.view(np.int16)).cuda()
+        dd = torch.empty_like(d)
+        ctx.compute_dists(d.data_ptr(), cols * 2, dd.data_ptr(), cols * 2, rows, cols, intr)
+        keep.append((d, dd))
+        views.append((dd.data_ptr(), R.reshape(-1), t))
+    # voxels each view updates: weight sum before / after one pass from a cleared volume (weights only grow)
+    updated = []
+    for ptr, R, t in views:
+        before = int((vol >> 16).sum(dtype=torch.int64).item())
+        ctx.integrate(desc, ptr, cols * 2, rows, cols, R, t, intr)
+        updated.append(int((vol >> 16).sum(dtype=torch.int64).item()) - before)
+    # brick classes in a pass of their own: the counters are contended atomics and would be in the timing
+    ctx.set_option("brick_stats", 1)
+    for ptr, R, t in views:
+        ctx.integrate(desc, ptr, cols * 2, rows, cols, R, t, intr)
+    bricks = ctx.brick_stats()
+    ctx.set_option("brick_stats", 0)
+    ctx.set_option("kernel_timing", 1)
+    reps = 5
+    for _ in range(reps):
+        for ptr, R, t in views:
+            ctx.integrate(desc, ptr, cols * 2, rows, cols, R, t, intr)
+    ms, _ = ctx.kernel_times(reps * len(views))
+    ctx.set_option("kernel_timing", 0)
+    per_view = [sum(ms[i::len(views)]) / reps for i in range(len(views))]
+    mean_ms = sum(per_view) / len(per_view)
+    mean_upd = sum(updated) / len(updated)
+    alg = 8 * mean_upd + 2 * rows * cols
+    total = max(sum(bricks.values()), 1)
+    return {"workload": "512^3, 8 views of the S2 orbit (ground plane + 3 spheres, 1 mm noise), one frame per launch",
+            "kernel_ms_mean": round(mean_ms, 4), "kernel_ms_per_view": [round(v, 4) for v in per_view],
+            "voxels_updated_mean": int(mean_upd), "Gvox_updated_per_s": round(mean_upd / (mean_ms * 1e-3) / 1e9, 1),
+            "Gvox_visited_per_s": round(n ** 3 / (mean_ms * 1e-3) / 1e9, 1),
+            "algorithmic_GBps": round(alg / (mean_ms * 1e-3) / 1e9, 1),
+            "frac_of_hbm_peak": round(alg / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "wave_bricks": {k: round(v / total, 4) for k, v in bricks.items()},
+            "note": "bound by the per-voxel path of the bricks that hold surface, not by HBM: only updated voxels "
+                    "count as algorithmic bytes (SURVEY.md 8d)"}
+
+
 def load_traffic(workload_key):
     """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/traffic.json), or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -470,6 +522,10 @@ def main():
             except Exception as e:  # secondary: never take the headline down with it
                 out["next_rows"] = {"error": "%s: %s" % (type(e).__name__, e)}
             if not args.no_loop:
+                try:
+                    out["orbit_views"] = orbit_views_row(ctx, torch, capi, synth)
+                except Exception as e:
+                    out["orbit_views"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 try:
                     out["kinfu_loop"] = kinfu_loop_row(ctx)
                 except Exception as e:
