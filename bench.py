@@ -143,7 +143,7 @@ def next_rows(ctx, torch, capi, synth, with_cpu):
     ntri = ctx.marching_cubes(desc, 2, vs[0])
     tri = torch.empty((max(ntri, 1), 9), dtype=torch.float32, device="cuda")
     ms = timed(lambda: ctx.marching_cubes(desc, 2, vs[0], tri.data_ptr(), ntri), 5)
-    mc_bytes = 2 * 4 * n ** 3 + 36 * ntri
+    mc_bytes = 4 * n ** 3 + 36 * ntri  # the least any extraction moves: one read of the volume + the triangles
     out["marching_cubes"] = {"ms_both_passes": round(ms, 4), "triangles": ntri, "algorithmic_bytes": mc_bytes,
                              "achieved_GBps": round(mc_bytes / (ms * 1e-3) / 1e9, 1),
                              "frac_of_hbm_peak": round(mc_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -169,18 +169,15 @@ def next_rows(ctx, torch, capi, synth, with_cpu):
                             "achieved_GBps": round(cl_bytes / (ms * 1e-3) / 1e9, 1),
                             "frac_of_hbm_peak": round(cl_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
     if with_cpu:
-        import oracle
-
-        sub = 128  # bounded sample: the central 128^3 block of the same volume
-        lo = (n - sub) // 2
-        block = vol.view(n, n, n)[lo:lo + sub, lo:lo + sub, lo:lo + sub].contiguous().cpu().numpy().view(np.uint32)
-        t0 = time.perf_counter()
-        cpu_tris = oracle.marching_cubes(block.reshape(-1), (sub, sub, sub), 2, vs[0])
-        dt = time.perf_counter() - t0
-        out["marching_cubes"]["cpu_baseline"] = {
-            "value": round(sub ** 3 / (dt / 2) / 1e9, 4), "unit": "Gvox/s", "cores": 1, "kind": "port",
-            "sample": "oracle restatement of marchingCubesCPU's core on the central 128^3 block (%d triangles), "
-                      "count + emit runs" % len(cpu_tris)}
+        out["marching_cubes"]["cpu_baseline"] = c1_cpu_baseline(synth)
+        # the same C1 volume on the GPU, for a like-for-like figure
+        c1 = torch.from_numpy(synth.sphere_tsdf_volume(256, 25.6).view(np.int32)).cuda()
+        c1desc = capi.volume_desc(c1.data_ptr(), (256, 256, 256), (1.0, 1.0, 1.0), 4.0, synth.MAX_WEIGHT)
+        n1 = ctx.marching_cubes(c1desc, 4, 1.0)
+        t1 = torch.empty((max(n1, 1), 9), dtype=torch.float32, device="cuda")
+        ms1 = timed(lambda: ctx.marching_cubes(c1desc, 4, 1.0, t1.data_ptr(), n1), 5)
+        out["marching_cubes"]["c1_sphere_256"] = {"ms_both_passes": round(ms1, 4), "triangles": n1,
+                                                  "Gvox_per_s": round(256 ** 3 / (ms1 * 1e-3) / 1e9, 1)}
     return out
 
 
@@ -261,6 +258,208 @@ def orbit_views_row(ctx, torch, capi, synth):
                     "count as algorithmic bytes (SURVEY.md 8d)"}
 
 
+# ---- config 5 of BASELINE.json: 2048^3 over 8 GPUs, multi-camera batched fusion + GPU marching cubes ------------
+C5_EDGE = 2048           # the global volume of north_star's scaling target
+C5_LAYERS_PER_RANK = 256  # 2048 / 8: every rank holds 2048 x 2048 x 256 voxels (4 GiB) at every N -> weak scaling
+C5_CAMERAS = (0, 75, 150, 225)  # four views of the S2 orbit rig, 90 degrees apart, folded in one sweep
+
+
+def c5_slab(world, rank):
+    """Layers of rank `rank`: the N ranks hold the central 256 * N layers of the 2048-layer volume (N = 8: all of it)."""
+    lo = C5_EDGE // 2 - C5_LAYERS_PER_RANK * world // 2
+    return lo + C5_LAYERS_PER_RANK * rank, lo + C5_LAYERS_PER_RANK * (rank + 1)
+
+
+def c1_cpu_baseline(synth):
+    """Config C1: Yak's CPU marching cubes (its restatement: the reference's needs PCL/VTK) over the
+    256^3 analytic sphere of the reference's stand-alone program, at 1 and at all threads."""
+    import oracle
+
+    n = 256
+    vol = synth.sphere_tsdf_volume(n, 25.6)
+    threads = min(oracle.max_threads(), os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    tris = oracle.marching_cubes(vol, (n, n, n), 4, 1.0)
+    t1 = time.perf_counter() - t0
+    reps, tm = 0, 0.0
+    while tm < 4.0 and reps < 200:
+        t0 = time.perf_counter()
+        oracle.marching_cubes(vol, (n, n, n), 4, 1.0, nthreads=threads)
+        tm += time.perf_counter() - t0
+        reps += 1
+    return {"value": round(n ** 3 / (tm / reps) / 1e9, 4), "unit": "Gvox/s", "cores": threads, "kind": "port",
+            "value_1thread": round(n ** 3 / t1 / 1e9, 4), "triangles": int(len(tris)),
+            "sample": "oracle restatement of marchingCubesCPU (count + emit passes, x slices in parallel as the "
+                      "reference's OpenMP loop) over the 256^3 sphere of radius 25.6 voxels (BASELINE config 1), "
+                      "%d repetitions at %d threads + 1 at 1 thread" % (reps, threads)}
+
+
+def run_c5(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, emulate):
+    """One step = ONE SWEEP of the rank's 2048 x 2048 x 256 slab folding the K = 4 camera frames
+    (yakhip_integrate_batch); marching cubes over the slab is timed beside it (it runs once per scan, not per
+    sweep).  value = voxel updates of all ranks and all K frames per second of the slowest rank."""
+    n = C5_EDGE
+    dims, vs, tr = synth.volume_geometry(n)
+    z0, z1 = c5_slab(world, rank)
+    z1h = min(z1 + 1, n)  # one layer of overlap for marching cubes (include/yakhip.h); integrated redundantly
+    layers = z1h - z0
+    rows, cols, intr = synth.ROWS, synth.COLS, synth.INTR
+    ctx = capi.Context(local_rank)
+    if args.z_chunk:
+        ctx.set_option("z_chunk", args.z_chunk)
+    if args.no_brick:
+        ctx.set_option("brick_test", 0)
+    vol = torch.empty(layers * n * n, dtype=torch.int32, device="cuda")
+    held = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT, z0, z1h)
+    frames, keep = [], []
+    for f in C5_CAMERAS:
+        depth, R, t = synth.scene_s2(f)
+        d = torch.from_numpy(depth.view(np.int16)).cuda()
+        dd = torch.empty_like(d)
+        ctx.compute_dists(d.data_ptr(), cols * 2, dd.data_ptr(), cols * 2, rows, cols, intr)
+        keep.append((d, dd, depth, R, t))
+        frames.append((dd.data_ptr(), cols * 2, rows, cols, R.reshape(-1), t, intr))
+    K = len(frames)
+
+    def step():
+        ctx.integrate_batch(held, frames)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx.set_option("kernel_timing", 1)
+    ctx.clear_volume(held)
+    step()
+    torch.cuda.synchronize()
+    own = vol[: (z1 - z0) * n * n]  # the overlap layer belongs to the next rank: not counted
+    w = own >> 16
+    touched = int((w != 0).sum().item())
+    updates = int(w.sum(dtype=torch.int64).item())  # every update adds 1 to a weight (K < max_weight)
+    touched_held = int(((vol >> 16) != 0).sum().item())
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    series, _ = ctx.kernel_times(1 + args.warmup + args.steps)
+    ctx.set_option("kernel_timing", 0)
+    timed = series[1 + args.warmup:]
+    kernel_ms = sum(timed) / max(len(timed), 1)
+
+    # marching cubes over the slab (count, scan, emit), blocking calls
+    ntri = ctx.marching_cubes(held, 2, vs[0])
+    tri = torch.empty((max(ntri, 1), 9), dtype=torch.float32, device="cuda")
+    ctx.marching_cubes(held, 2, vs[0], tri.data_ptr(), ntri)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mc_reps = 3
+    for _ in range(mc_reps):
+        ctx.marching_cubes(held, 2, vs[0], tri.data_ptr(), ntri)
+    mc_ms = (time.perf_counter() - t0) / mc_reps * 1e3
+    del tri
+
+    totals = torch.tensor([elapsed, kernel_ms, mc_ms, float(updates), float(touched), float(ntri)], dtype=torch.float64,
+                          device="cpu" if share_gpu else "cuda")
+    if dist is not None:
+        mx, sm = totals.clone(), totals.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, kernel_ms, mc_ms = float(mx[0]), float(mx[1]), float(mx[2])
+        updates_total, touched_total, ntri_total = int(sm[3]), int(sm[4]), int(sm[5])
+    else:
+        updates_total, touched_total, ntri_total = updates, touched, ntri
+    if rank == 0 or emulate:
+        # algorithmic bytes of ONE launch on ONE GPU (SURVEY.md 8d, batched mode): the touched voxels are read and
+        # written once for all K frames, plus one pass over each of the K half images
+        alg_bytes = 8 * touched_held + K * 2 * rows * cols
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        visited = layers * n * n
+        mc_bytes = 4 * visited + 36 * ntri  # the least any extraction moves: one read of the slab + the triangles
+        out = {
+            "metric": "voxel updates/sec",
+            "value": round(updates_total * args.steps / elapsed / 1e9, 3),
+            "unit": "Gvox/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 5: %dx%dx%d of a %d^3 volume (2048x2048x256 voxels = 4 GiB per GPU, z-slabs, "
+                                   "voxel %.2f mm), one sweep per step folds %d synthetic %dx%d depth frames (orbit rig, 90 "
+                                   "degrees apart, yakhip_integrate_batch); GPU marching cubes over the slab timed beside it"
+                                   % (n, n, C5_LAYERS_PER_RANK * world, n, vs[0] * 1e3, K, cols, rows),
+                       "frames_per_step": K, "voxel_updates_per_step": updates_total, "voxels_touched_per_step": touched_total,
+                       "voxels_visited_per_step": K * C5_LAYERS_PER_RANK * world * n * n, "voxel_bytes": 4,
+                       "visited_Gvox_per_s": round(K * C5_LAYERS_PER_RANK * world * n * n * args.steps / elapsed / 1e9, 1),
+                       "parallelism": "z-slab x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "kernel": "yakhip::integrate_batch_kernel<4, true>", "kernel_ms": round(kernel_ms, 5),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "rank 0's slab; bound by the per-voxel path of the bricks that hold surface, not by HBM "
+                                 "(only touched voxels count as algorithmic bytes)"},
+            "marching_cubes": {"ms_per_extraction_slowest_rank": round(mc_ms, 4), "triangles": ntri_total,
+                               "Gvox_per_s_per_gpu": round(visited / (mc_ms * 1e-3) / 1e9, 1),
+                               "algorithmic_GBps_rank0": round(mc_bytes / (mc_ms * 1e-3) / 1e9, 1),
+                               "frac_of_hbm_peak_rank0": round(mc_bytes / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                               "how": "count pass, scan, emit pass over the slab + 1 overlap layer; wall time of the "
+                                      "blocking call (the host reads the count back); algorithmic bytes = one read of the "
+                                      "slab + 36 B per triangle (the emit pass re-reads only tiles that hold surface)"},
+        }
+        if emulate:
+            out["config"]["emulated_rank"] = "%d of %d (this GPU's slab only: value is per GPU)" % (rank, world)
+            out["n_gpus"] = 1
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle
+
+            threads = min(oracle.max_threads(), os.cpu_count() or 1)
+            # bounded sample: the K frames applied in order to the slab's first 2 and first 10 layers.  A slab that
+            # starts at layer z0 costs the port z0 replayed additions per column before its first voxel (as it costs
+            # the GPU kernel's chunk starts), so T(layers) = a + b * layers: the two samples give a and b, and the
+            # figure reported is for the whole slab, T(256), against the updates the GPU counted for it.
+            dists_host = [dd.cpu().numpy().view(np.uint16) for d, dd, depth, R, t in keep]
+
+            def cpu_pass(k_layers, budget_s):
+                slab = np.zeros(n * n * k_layers, dtype=np.uint32)
+                reps, tm = 0, 0.0
+                while tm < budget_s and reps < 50:
+                    slab[:] = 0
+                    t0 = time.perf_counter()
+                    for dh, (d, dd, depth, R, t) in zip(dists_host, keep):
+                        oracle.integrate(slab, dims, vs, tr, synth.MAX_WEIGHT, dh, R, t, intr, z0=z0, z1=z0 + k_layers,
+                                         nthreads=threads)
+                    tm += time.perf_counter() - t0
+                    reps += 1
+                return tm / reps, reps
+
+            t2, r2 = cpu_pass(2, 4.0)
+            t10, r10 = cpu_pass(10, 6.0)
+            b = max((t10 - t2) / 8.0, 0.0)
+            t_slab = t2 + b * (C5_LAYERS_PER_RANK - 2)
+            out["cpu_baseline"] = {
+                "value": round(updates / t_slab / 1e9, 4), "unit": "Gvox/s", "cores": threads, "kind": "port",
+                "visited_Gvox_per_s": round(K * n * n * C5_LAYERS_PER_RANK / t_slab / 1e9, 4),
+                "sample": "scalar C oracle (OpenMP over y), the %d frames applied in order to layers [%d, %d) (%.3f s, %d "
+                          "repetitions) and [%d, %d) (%.3f s, %d repetitions) of the slab at %d threads; extrapolated "
+                          "linearly to the slab's %d layers (%.2f s per sweep)" % (
+                              K, z0, z0 + 2, t2, r2, z0, z0 + 10, t10, r10, threads, C5_LAYERS_PER_RANK, t_slab)}
+            out["marching_cubes"]["cpu_baseline"] = c1_cpu_baseline(synth)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
 def load_traffic(workload_key):
     """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/traffic.json), or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -280,6 +479,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--scene", default="s0", choices=["s0", "s1", "s2"],
                     help="s1 = sphere+wall, s2 = a view of the orbit scene (partial updates); N=1 only")
+    ap.add_argument("--config", default=os.environ.get("YAK_BENCH_CONFIG", "c2"), choices=["c2", "c5"],
+                    help="c2 (default): BASELINE config 2, 512^3 per GPU, one frame per step.  c5: BASELINE config 5, "
+                         "north_star's scaling target: 2048x2048x256 per GPU (2048^3 on 8), 4 cameras per sweep + GPU "
+                         "marching cubes (also through the environment: YAK_BENCH_CONFIG=c5)")
     ap.add_argument("--z-chunk", type=int, default=0)
     ap.add_argument("--vx", type=int, default=0, help="cap on voxels per lane (tuning)")
     ap.add_argument("--tile", type=int, default=0, help="wave footprint: log2 lanes along x, 3..6 (tuning)")
@@ -328,6 +531,10 @@ def main():
     # ---- workload ---------------------------------------------------------------------------------
     if emulate:
         world, rank = emulate
+    if args.config == "c5":
+        if world not in (1, 2, 4, 8):
+            sys.exit("config c5: supported world sizes 1, 2, 4, 8")
+        return run_c5(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, emulate)
     if world not in GLOBAL_DIMS:
         sys.exit("supported world sizes: %s" % sorted(GLOBAL_DIMS))
     dims = GLOBAL_DIMS[world]

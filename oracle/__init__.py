@@ -85,6 +85,9 @@ def lib():
                                          np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), _u64p, vp]
         L.yko_marching_cubes.restype = C.c_uint64
         L.yko_marching_cubes.argtypes = [_u32p, _i32p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.yko_marching_cubes_mt.restype = C.c_uint64
+        L.yko_marching_cubes_mt.argtypes = [_u32p, _i32p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_uint64, C.c_int]
         L.yko_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -301,14 +304,23 @@ def unpack_case_table():
     return tri, conn
 
 
-def marching_cubes(volume, dims, min_weight=4, scale=1.0, tables=None):
-    """Returns triangles float32 (n, 3, 3) in the reference's serial visiting order."""
+def marching_cubes(volume, dims, min_weight=4, scale=1.0, tables=None, nthreads=1):
+    """Returns triangles float32 (n, 3, 3) in the reference's serial visiting order (nthreads > 1: the x slices in
+    parallel, as the reference's OpenMP loop; same order)."""
     dims = np.ascontiguousarray(dims, dtype=np.int32)
     vol = np.ascontiguousarray(volume, dtype=np.uint32).reshape(-1)
     assert vol.size == int(dims[0]) * int(dims[1]) * int(dims[2])
     tri, conn = (tables if tables is not None else mc_tables()[:2])
     tri = np.ascontiguousarray(tri, dtype=np.int32)
     conn = np.ascontiguousarray(conn, dtype=np.int32)
+    if nthreads > 1:
+        n = lib().yko_marching_cubes_mt(vol, dims, int(min_weight), float(scale), tri.ctypes.data, conn.ctypes.data, None,
+                                        0, int(nthreads))
+        out = np.empty((n, 3, 3), dtype=np.float32)
+        if n:
+            assert lib().yko_marching_cubes_mt(vol, dims, int(min_weight), float(scale), tri.ctypes.data,
+                                               conn.ctypes.data, out.ctypes.data, n, int(nthreads)) == n
+        return out
     n = lib().yko_marching_cubes(vol, dims, int(min_weight), float(scale), tri.ctypes.data, conn.ctypes.data, None, 0)
     out = np.empty((n, 3, 3), dtype=np.float32)
     if n:

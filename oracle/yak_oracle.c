@@ -860,12 +860,14 @@ static const int mc_cube_offsets[8][3] = {
   { 1, 1, 0 }, { 1, 0, 0 }, { 0, 0, 0 }, { 0, 1, 0 }, { 1, 1, 1 }, { 1, 0, 1 }, { 0, 0, 1 }, { 0, 1, 1 },
 };
 
-uint64_t yko_marching_cubes(const uint32_t* volume, const int dims[3], int min_weight, double scale,
-                            const int* tri_table, const int* edge_connections, float* triangles, uint64_t capacity)
+/* the cubes of one x index (the reference's OpenMP loop is over x, :163-170); triangles[] starts at this
+ * slice's first triangle, capacity counts from there */
+static uint64_t mc_slice(const uint32_t* volume, const int dims[3], int min_weight, double scale, const int* tri_table,
+                         const int* edge_connections, int x, float* triangles, uint64_t capacity)
 {
   const int X = dims[0], Y = dims[1], Z = dims[2];
   uint64_t n = 0;
-  for (int x = 0; x + 1 < X; ++x) /* :164-170 with x-1, y-1, z-1 */
+  {
     for (int y = 0; y + 1 < Y; ++y)
       for (int z = 0; z + 1 < Z; ++z)
       {
@@ -920,6 +922,46 @@ uint64_t yko_marching_cubes(const uint32_t* volume, const int dims[3], int min_w
           ++n;
         }
       }
+  }
+  return n;
+}
+
+uint64_t yko_marching_cubes(const uint32_t* volume, const int dims[3], int min_weight, double scale,
+                            const int* tri_table, const int* edge_connections, float* triangles, uint64_t capacity)
+{
+  uint64_t n = 0;
+  for (int x = 0; x + 1 < dims[0]; ++x) /* :164-170 with x-1, y-1, z-1 */
+    n += mc_slice(volume, dims, min_weight, scale, tri_table, edge_connections, x, triangles ? triangles + 9 * n : NULL,
+                  capacity > n ? capacity - n : 0);
+  return n;
+}
+
+/* The same over x in parallel, as the reference runs it (#pragma omp parallel for over x, :163): a counting pass,
+ * a prefix sum over the x slices, an emitting pass into each slice's own range -- the triangles come out in the
+ * serial routine's order (the reference's own order is nondeterministic: its inserts share one critical
+ * section, :165-171).  For the timed CPU baseline of bench.py. */
+uint64_t yko_marching_cubes_mt(const uint32_t* volume, const int dims[3], int min_weight, double scale,
+                               const int* tri_table, const int* edge_connections, float* triangles, uint64_t capacity,
+                               int nthreads)
+{
+  const int nx = dims[0] > 1 ? dims[0] - 1 : 0;
+  uint64_t* start = (uint64_t*)calloc((size_t)nx + 1, sizeof(uint64_t));
+  if (!start)
+    return 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+  for (int x = 0; x < nx; ++x)
+    start[x + 1] = mc_slice(volume, dims, min_weight, scale, tri_table, edge_connections, x, NULL, 0);
+  for (int x = 0; x < nx; ++x)
+    start[x + 1] += start[x];
+  const uint64_t n = start[nx];
+  if (triangles && n <= capacity)
+  {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int x = 0; x < nx; ++x)
+      mc_slice(volume, dims, min_weight, scale, tri_table, edge_connections, x, triangles + 9 * start[x],
+               start[x + 1] - start[x]);
+  }
+  free(start);
   return n;
 }
 

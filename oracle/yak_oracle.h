@@ -144,6 +144,10 @@ void yko_icp_accumulate(const float R[9], const float t[3], const float intr[4],
  */
 uint64_t yko_marching_cubes(const uint32_t* volume, const int dims[3], int min_weight, double scale,
                             const int* tri_table, const int* edge_connections, float* triangles, uint64_t capacity);
+/* the same, the x slices in parallel (the reference's OpenMP loop, marching_cubes.cpp:163); same triangle order */
+uint64_t yko_marching_cubes_mt(const uint32_t* volume, const int dims[3], int min_weight, double scale,
+                               const int* tri_table, const int* edge_connections, float* triangles, uint64_t capacity,
+                               int nthreads);
 
 /* ---- cloud extraction: src/cuda/tsdf_volume.cu:464-800 (FullScan6, ExtractNormals) --------------
  * parity unpinned: the reference holds no vector for it (and its own output order is nondeterministic:

@@ -123,3 +123,14 @@ def test_sphere_c1_geometry():
     t2 = oracle.marching_cubes(vol, (n, n, n), 4, 0.01)
     assert np.array_equal(t2, (np.float64(0.01) * tris.astype(np.float64)).astype(np.float32))
     assert len(oracle.marching_cubes(vol, (n, n, n), min_weight=5)) == 0
+
+
+def test_threaded_routine_equals_the_serial_one():
+    """yko_marching_cubes_mt (x slices in parallel, the reference's OpenMP loop) gives the serial routine's
+    triangles in the serial routine's order; it is what bench.py times at 1 and max threads (config C1)."""
+    n = 48
+    vol = sphere_volume(n, 15.7)
+    a = oracle.marching_cubes(vol, (n, n, n), 4, 0.01)
+    b = oracle.marching_cubes(vol, (n, n, n), 4, 0.01, nthreads=4)
+    assert len(a) > 1000 and np.array_equal(a, b)
+    assert len(oracle.marching_cubes(vol, (n, n, n), 5, 1.0, nthreads=3)) == 0

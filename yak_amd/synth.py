@@ -121,3 +121,15 @@ def scene_s2(frame, n_frames=300, radius=3.2, noise_mm=0.0):
     depth = render_depth(R_c2v, eye, planes=[S2_GROUND], spheres=S2_SPHERES, noise_mm=noise_mm, seed=12345 + frame)
     R, t = vol2cam(R_c2v, eye)
     return depth, R, t
+
+
+def sphere_tsdf_volume(n, radius_vox, trunc_vox=4.0, weight=4):
+    """Config C1 of BASELINE.json: the analytic sphere of the reference's stand-alone marching-cubes program
+    (yak/src/mc/marching_cubes_tests.cpp:19-43: radius 25.6 voxels in 256^3) as a packed TSDF volume --
+    clamp(d / trunc, -1, 1) rounded to half (nearest even), constant weight.  uint32, x fastest."""
+    c = (n - 1) / 2.0
+    z, y, x = np.meshgrid(np.arange(n, dtype=np.float32), np.arange(n, dtype=np.float32),
+                          np.arange(n, dtype=np.float32), indexing="ij")
+    d = np.sqrt((x - c) ** 2 + (y - c) ** 2 + (z - c) ** 2) - np.float32(radius_vox)
+    f = np.clip(d / np.float32(trunc_vox), -1, 1).astype(np.float16)
+    return (f.view(np.uint16).astype(np.uint32) | (np.uint32(weight) << 16)).reshape(-1)
