@@ -87,7 +87,8 @@ const char* yakhip_last_error(void);
  * "checkpoint" (0/1: slabs with z0 >= 64 start from column positions computed in closed form instead of
  * replaying z0 additions per column), "tile" (0 or 3..6: wave footprint in the layer), "tile_side" (0/1: a workgroup's waves stacked in y / side by side in x), "mc_z_chunk"
  * (marching-cubes tile depth, 0 = auto), "kernel_timing" (0/1, see yakhip_ctx_kernel_time), "brick_stats" (0/1, see
- * yakhip_ctx_brick_stats), "zu" (ignored).
+ * yakhip_ctx_brick_stats), "composite_capacity" (list slots of yakhip_raycast_sharded's second step, 0 = auto),
+ * "zu" (ignored).
  * Unknown key or value -> YAKHIP_EINVAL. */
 int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value);
 /* Measurement aid with no counterpart in the reference (its only timers are the never-invoked
@@ -250,6 +251,57 @@ int yakhip_raycast_resolve(yakhip_ctx* ctx, const yakhip_volume* vol, int z_own0
  * vol->data, z0, z1 are not looked at beyond the usual validity checks. */
 int yakhip_raycast_halo(const yakhip_volume* vol, float step_factor, float gradient_delta_factor, int* layers);
 
+/* ---- the exchange steps of a z-slab sharded volume ----------------------------------
+ * No counterpart in the reference, which has one GPU and no communication.  A communicator
+ * joins `world` ranks, one per context: GPUs of one node as processes or as threads of one process.
+ * integrate needs none of this (every rank integrates its own layers of the same frame); the tracking side
+ * has two exchange steps, both enqueued on the context's stream without a host wait when the transport is RCCL:
+ * the composite of the per-slab ray casts and the sum of the per-rank ICP normal equations. */
+typedef struct yakhip_comm yakhip_comm;
+#define YAKHIP_SUM_F32 0
+#define YAKHIP_MIN_I32 1
+#define YAKHIP_SUM_I32 2
+#define YAKHIP_UNIQUE_ID_BYTES 128
+/* RCCL transport (ncclAllReduce over xGMI on the context's stream).  One rank calls yakhip_comm_unique_id and
+ * hands the 128 bytes to the others (the caller's business: a pipe, a file, MPI, torch.distributed); then every
+ * rank calls yakhip_comm_create_rccl with its own context -- concurrently, it returns when all have joined.
+ * librccl is opened on first use; YAKHIP_ENOGPU if it cannot be.  RCCL accepts one rank per GPU. */
+int yakhip_comm_unique_id(void* id_out, size_t bytes);
+int yakhip_comm_create_rccl(yakhip_ctx* ctx, yakhip_comm** out, const void* unique_id, int world, int rank);
+/* Ranks that are threads of ONE process, on the same GPU or on different ones: the values meet in host memory
+ * behind a barrier (blocking; every rank must make the same calls in the same order, each from its own
+ * thread).  Fills comms_out[0 .. world).  For tests on a one-GPU box and as a fallback transport. */
+int yakhip_comm_create_local(int world, yakhip_comm** comms_out);
+/* A caller-supplied all-reduce (over MPI, torch.distributed, ...): fn(user, buf_dev, count, op, hip_stream) must
+ * leave the reduction over all ranks of the `count` 4-byte values at buf_dev (op = YAKHIP_SUM_F32 / MIN_I32 /
+ * SUM_I32) visible to work enqueued later on hip_stream, with the SAME bits on every rank; returns 0 or an
+ * error code (passed through). */
+typedef int (*yakhip_allreduce_fn)(void* user, void* buf_dev, size_t count, int op, void* hip_stream);
+int yakhip_comm_create_custom(yakhip_comm** out, int world, int rank, yakhip_allreduce_fn fn, void* user);
+int yakhip_comm_destroy(yakhip_comm* comm);
+int yakhip_comm_info(const yakhip_comm* comm, int* rank, int* world);
+/* In-place all-reduce of `count` 4-byte values in device memory, ordered on the context's stream. */
+int yakhip_comm_allreduce(yakhip_ctx* ctx, yakhip_comm* comm, void* buf_dev, size_t count, int op);
+
+/* Ray cast of a sharded volume in one call: yakhip_raycast_slab on this rank's layers, the composite over the
+ * ranks (all-reduce MIN over the keys, all-reduce SUM over the payload bits of the winners),
+ * yakhip_raycast_resolve, and the composite of the few pixels that call settled (one more all-reduce over a list
+ * of fixed capacity).  Arguments as yakhip_raycast_slab; on return (stream-ordered, not waited for) points /
+ * depth / normals hold, on EVERY rank, what yakhip_raycast_points / _depth give on the whole volume, bit for
+ * bit, and keys the composited keys.  Per call: 3 collectives -- 4 B, then 28 B per pixel, then 32 B per list
+ * slot (capacity max(4096, pixels / 64); yakhip_comm_status reports a frame that needed more).
+ * The communicator owns the scratch (about 40 B per pixel), allocated on first use. */
+int yakhip_raycast_sharded(yakhip_ctx* ctx, yakhip_comm* comm, const yakhip_volume* vol, int z_own0, int z_own1,
+                           const float R[9], const float t[3], const float Rinv[9], const float intr[4],
+                           float step_factor, float gradient_delta_factor, void* points_dev, size_t points_pitch,
+                           void* depth_dev, size_t depth_pitch, void* normals_dev, size_t normals_pitch, void* keys_dev,
+                           size_t keys_pitch, int rows, int cols);
+/* BLOCKING.  status[0] = pixels the last yakhip_raycast_sharded call had to settle in its second step,
+ * status[1] = calls since the last query whose list overflowed its capacity (their surplus pixels hold the
+ * refined point instead of the normal: repeat such a frame's ray cast after
+ * yakhip_ctx_set_option(ctx, "composite_capacity", pixels)). */
+int yakhip_comm_status(yakhip_ctx* ctx, yakhip_comm* comm, unsigned status[2]);
+
 /* ---- tracking side: depth pre-processing and projective ICP ------------
  * Depth images: uint16 millimetres; point / normal maps: float4 {x, y, z, w}, NaN = no data.  All
  * row-pitched (pitch in bytes; multiple of 2 resp. 16). */
@@ -331,6 +383,17 @@ typedef struct yakhip_icp_level
 int yakhip_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], float dist_thres,
                         float angle_thres, const yakhip_icp_level* levels, int n_levels, float R_out[9], float t_out[3],
                         int* ok);
+
+/* yakhip_icp_estimate over the ranks of a communicator: every rank passes the SAME maps (the composited
+ * model maps, the replicated current maps) and accumulates the rows [rows * rank / world, rows * (rank + 1) /
+ * world) of every level; the 33 sums of each linearisation are all-reduced on the stream, every rank solves
+ * the same 6 x 6 system from the same bits and ends with the same pose.  With the RCCL transport the whole
+ * schedule (per linearisation: accumulate launch, 33-wave reduction, ncclAllReduce of 132 bytes) is enqueued
+ * back to back and the host waits once.  BLOCKING (returns the pose).  Sums agree with the one-GPU estimate to
+ * rounding (the order of the additions differs), counts exactly. */
+int yakhip_icp_estimate_sharded(yakhip_ctx* ctx, yakhip_comm* comm, const float R[9], const float t[3],
+                                const float intr[4], float dist_thres, float angle_thres, const yakhip_icp_level* levels,
+                                int n_levels, float R_out[9], float t_out[3], int* ok);
 
 /* ---- surface extraction -------------------------------------------------- */
 

@@ -23,7 +23,13 @@ EXPORTS = [
     "yakhip_resize_points_normals", "yakhip_icp_accumulate", "yakhip_icp_accumulate_rows", "yakhip_icp_estimate",
     "yakhip_marching_cubes", "yakhip_weld_vertices", "yakhip_extract_cloud", "yakhip_extract_normals",
     "yakhip_render_image_points", "yakhip_render_image_depth", "yakhip_render_tangent_colors",
+    "yakhip_comm_unique_id", "yakhip_comm_create_rccl", "yakhip_comm_create_local", "yakhip_comm_create_custom",
+    "yakhip_comm_destroy", "yakhip_comm_info", "yakhip_comm_allreduce", "yakhip_comm_status",
+    "yakhip_raycast_sharded", "yakhip_icp_estimate_sharded",
 ]
+
+SUM_F32, MIN_I32, SUM_I32 = 0, 1, 2
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 
 
 class YakHipError(RuntimeError):
@@ -131,6 +137,18 @@ def load():
         "yakhip_render_tangent_colors": [vp, vp, sz, i, i, vp, sz],
         "yakhip_icp_accumulate": [vp, fp, fp, fp, i, C.c_float, C.c_float, vp, sz, vp, sz, vp, sz, vp, sz, i, i, fp,
                                   C.POINTER(i)],
+        "yakhip_comm_unique_id": [vp, sz],
+        "yakhip_comm_create_rccl": [vp, C.POINTER(vp), vp, i, i],
+        "yakhip_comm_create_local": [i, C.POINTER(vp)],
+        "yakhip_comm_create_custom": [C.POINTER(vp), i, i, ALLREDUCE_FN, vp],
+        "yakhip_comm_destroy": [vp],
+        "yakhip_comm_info": [vp, C.POINTER(i), C.POINTER(i)],
+        "yakhip_comm_allreduce": [vp, vp, vp, sz, i],
+        "yakhip_comm_status": [vp, vp, C.POINTER(C.c_uint)],
+        "yakhip_raycast_sharded": [vp, vp, volp, i, i, fp, fp, fp, fp, C.c_float, C.c_float, vp, sz, vp, sz, vp, sz, vp, sz,
+                                   i, i],
+        "yakhip_icp_estimate_sharded": [vp, vp, fp, fp, fp, C.c_float, C.c_float, C.POINTER(IcpLevel), i, fp, fp,
+                                        C.POINTER(i)],
     }
     for name, argtypes in sigs.items():
         fn = getattr(L, name)
@@ -380,6 +398,38 @@ class Context:
         _chk(load().yakhip_extract_normals(self._h, C.byref(vol), C.c_void_p(points_ptr), int(n_points), _f32(R, 9), _f32(t, 3),
                                            _f32(Rinv, 9), gradient_delta_factor, C.c_void_p(normals_ptr)))
 
+    # ---- sharded volume: the exchange steps (include/yakhip.h, yakhip_comm) ----
+    def allreduce(self, comm, buf_ptr, count, op):
+        _chk(load().yakhip_comm_allreduce(self._h, comm._h, C.c_void_p(buf_ptr), int(count), int(op)))
+
+    def raycast_sharded(self, comm, vol, z_own0, z_own1, R, t, Rinv, intr, keys_ptr, keys_pitch, normals_ptr, normals_pitch,
+                        rows, cols, points_ptr=None, points_pitch=0, depth_ptr=None, depth_pitch=0, step_factor=0.75,
+                        gradient_delta_factor=0.5):
+        """Slab ray cast + composite over the ranks + resolve + composite of the settled pixels; not waited for."""
+        _chk(load().yakhip_raycast_sharded(self._h, comm._h, C.byref(vol), int(z_own0), int(z_own1), _f32(R, 9), _f32(t, 3),
+                                           _f32(Rinv, 9), _f32(intr, 4), step_factor, gradient_delta_factor,
+                                           C.c_void_p(points_ptr), points_pitch, C.c_void_p(depth_ptr), depth_pitch,
+                                           C.c_void_p(normals_ptr), normals_pitch, C.c_void_p(keys_ptr), keys_pitch, rows,
+                                           cols))
+
+    def comm_status(self, comm):
+        """Blocking.  (pixels settled by the last sharded ray cast's second step, calls whose list overflowed)."""
+        out = (C.c_uint * 2)()
+        _chk(load().yakhip_comm_status(self._h, comm._h, out))
+        return int(out[0]), int(out[1])
+
+    def icp_estimate_sharded(self, comm, R, t, intr, dist_thres, angle_thres, levels):
+        """icp_estimate over the ranks of `comm` (row bands, all-reduced sums).  Blocking.  Returns (R, t, ok)."""
+        arr = (IcpLevel * len(levels))()
+        for d, (vc, nc, vp_, np_, pitch, rows, cols, iters) in zip(arr, levels):
+            d.vcurr, d.ncurr, d.vprev, d.nprev = vc, nc, vp_, np_
+            d.vcurr_pitch = d.ncurr_pitch = d.vprev_pitch = d.nprev_pitch = pitch
+            d.rows, d.cols, d.iterations = rows, cols, iters
+        Ro, to, ok = (C.c_float * 9)(), (C.c_float * 3)(), C.c_int(0)
+        _chk(load().yakhip_icp_estimate_sharded(self._h, comm._h, _f32(R, 9), _f32(t, 3), _f32(intr, 4), dist_thres,
+                                                angle_thres, arr, len(levels), Ro, to, C.byref(ok)))
+        return list(Ro), list(to), bool(ok.value)
+
     # ---- debug display: images are 4 bytes per pixel {b, g, r, 0} ----
     def render_image_points(self, points_ptr, points_pitch, normals_ptr, normals_pitch, rows, cols, light_pose, image_ptr,
                             image_pitch):
@@ -396,6 +446,50 @@ class Context:
     def render_tangent_colors(self, normals_ptr, normals_pitch, rows, cols, image_ptr, image_pitch):
         _chk(load().yakhip_render_tangent_colors(self._h, C.c_void_p(normals_ptr), normals_pitch, rows, cols,
                                                  C.c_void_p(image_ptr), image_pitch))
+
+
+class Comm:
+    """yakhip_comm: the ranks that share a z-slab sharded volume."""
+
+    def __init__(self, handle, keep=None):
+        self._h, self._keep = handle, keep
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        _chk(load().yakhip_comm_unique_id(buf, 128))
+        return bytes(buf)
+
+    @classmethod
+    def rccl(cls, ctx, unique_id, world, rank):
+        h = C.c_void_p()
+        _chk(load().yakhip_comm_create_rccl(ctx._h, C.byref(h), C.c_char_p(unique_id), int(world), int(rank)))
+        return cls(h)
+
+    @classmethod
+    def local(cls, world):
+        """`world` communicators for ranks that are threads of this process."""
+        arr = (C.c_void_p * world)()
+        _chk(load().yakhip_comm_create_local(int(world), arr))
+        return [cls(C.c_void_p(arr[r])) for r in range(world)]
+
+    @classmethod
+    def custom(cls, world, rank, fn):
+        """fn(buf_ptr, count, op, stream_ptr) -> 0: the caller's all-reduce (see include/yakhip.h)."""
+        cb = ALLREDUCE_FN(lambda user, buf, count, op, stream: int(fn(buf, count, op, stream) or 0))
+        h = C.c_void_p()
+        _chk(load().yakhip_comm_create_custom(C.byref(h), int(world), int(rank), cb, None))
+        return cls(h, keep=cb)
+
+    def info(self):
+        r, w = C.c_int(0), C.c_int(0)
+        _chk(load().yakhip_comm_info(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            load().yakhip_comm_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 def raycast_halo(vol, step_factor=0.75, gradient_delta_factor=0.5):

@@ -143,6 +143,7 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->stage[0] = ctx->stage[1] = nullptr;
   ctx->stage_done[0] = ctx->stage_done[1] = nullptr;
   ctx->kernel_timing = 0;
+  ctx->composite_capacity = 0;
   ctx->timing_used = 0;
   int rc = check(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
   if (rc != 0)
@@ -296,6 +297,13 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
     if (value != 0 && (value < 3 || value > 6))
       return fail(YAKHIP_EINVAL, "tile must be 0 (default) or 3..6");
     ctx->tile_shift = value;
+    return 0;
+  }
+  if (strcmp(key, "composite_capacity") == 0)
+  {
+    if (value < 0)
+      return fail(YAKHIP_EINVAL, "composite_capacity must be >= 0");
+    ctx->composite_capacity = value;
     return 0;
   }
   if (strcmp(key, "tile_side") == 0)
@@ -1166,6 +1174,48 @@ int yakhip_icp_accumulate_rows(yakhip_ctx* ctx, const float R[9], const float t[
                                sums_dev);
 }
 
+// One linearisation's host side, the reference's own control flow (projective_icp.cpp:212-228): unpack the 27
+// sums, determinant test, SVD solve, Tinc * corrected.  Returns false where estimateTransform returns false.
+static bool host_solve_step(const float sums[27], float Rc[9], float tc[3])
+{
+  double A[36], b[6], r[6];
+  int shift = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 7; ++j)
+    {
+      const double value = sums[shift++];
+      if (j == 6)
+        b[i] = value;
+      else
+        A[j * 6 + i] = A[i * 6 + j] = value;
+    }
+  const double det = yak::host::det6(A);
+  if (fabs(det) < 1e-15 || det != det)
+    return false;
+  yak::host::solve6_svd_symmetric(A, b, r);
+  // Affine3f(rvec, t) and Tinc * corrected, in the arithmetic of include/yak/kfusion/compat/linalg.hpp
+  const float rv[3] = { (float)r[0], (float)r[1], (float)r[2] };
+  float Ri[9] = { 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f };
+  const double th = sqrt((double)rv[0] * rv[0] + (double)rv[1] * rv[1] + (double)rv[2] * rv[2]);
+  if (th > 2.220446049250313e-16)
+  {
+    const double kx = rv[0] / th, ky = rv[1] / th, kz = rv[2] / th, c = cos(th), s = sin(th), v = 1.0 - c;
+    Ri[0] = (float)(c + kx * kx * v), Ri[1] = (float)(kx * ky * v - kz * s), Ri[2] = (float)(kx * kz * v + ky * s);
+    Ri[3] = (float)(ky * kx * v + kz * s), Ri[4] = (float)(c + ky * ky * v), Ri[5] = (float)(ky * kz * v - kx * s);
+    Ri[6] = (float)(kz * kx * v - ky * s), Ri[7] = (float)(kz * ky * v + kx * s), Ri[8] = (float)(c + kz * kz * v);
+  }
+  float Rn[9], tn[3];
+  for (int rr = 0; rr < 3; ++rr)
+  {
+    for (int cc = 0; cc < 3; ++cc)
+      Rn[3 * rr + cc] = Ri[3 * rr + 0] * Rc[0 + cc] + Ri[3 * rr + 1] * Rc[3 + cc] + Ri[3 * rr + 2] * Rc[6 + cc];
+    tn[rr] = (Ri[3 * rr + 0] * tc[0] + Ri[3 * rr + 1] * tc[1] + Ri[3 * rr + 2] * tc[2]) + (float)r[3 + rr];
+  }
+  memcpy(Rc, Rn, 9 * sizeof(float));
+  memcpy(tc, tn, 3 * sizeof(float));
+  return true;
+}
+
 int yakhip_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], float dist_thres,
                         float angle_thres, const yakhip_icp_level* levels, int n_levels, float R_out[9], float t_out[3],
                         int* ok)
@@ -1212,51 +1262,132 @@ int yakhip_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], con
                                       L.vprev_pitch, (const uint8_t*)L.nprev, L.nprev_pitch, L.rows, L.cols, sums,
                                       nullptr, 0, L.rows, nullptr)) != 0)
         return rc;
-      double A[36], b[6], r[6];
-      int shift = 0;
-      for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 7; ++j)
-        {
-          const double value = sums[shift++];
-          if (j == 6)
-            b[i] = value;
-          else
-            A[j * 6 + i] = A[i * 6 + j] = value;
-        }
-      const double det = yak::host::det6(A);
-      if (fabs(det) < 1e-15 || det != det)
+      if (!host_solve_step(sums, Rc, tc))
       {
         *ok = 0;
         memcpy(R_out, Rc, sizeof(Rc));
         memcpy(t_out, tc, sizeof(tc));
         return 0;
       }
-      yak::host::solve6_svd_symmetric(A, b, r);
-      // Affine3f(rvec, t) and Tinc * corrected, in the arithmetic of include/yak/kfusion/compat/linalg.hpp
-      const float rv[3] = { (float)r[0], (float)r[1], (float)r[2] };
-      float Ri[9] = { 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f };
-      const double th = sqrt((double)rv[0] * rv[0] + (double)rv[1] * rv[1] + (double)rv[2] * rv[2]);
-      if (th > 2.220446049250313e-16)
-      {
-        const double kx = rv[0] / th, ky = rv[1] / th, kz = rv[2] / th, c = cos(th), s = sin(th), v = 1.0 - c;
-        Ri[0] = (float)(c + kx * kx * v), Ri[1] = (float)(kx * ky * v - kz * s), Ri[2] = (float)(kx * kz * v + ky * s);
-        Ri[3] = (float)(ky * kx * v + kz * s), Ri[4] = (float)(c + ky * ky * v), Ri[5] = (float)(ky * kz * v - kx * s);
-        Ri[6] = (float)(kz * kx * v - ky * s), Ri[7] = (float)(kz * ky * v + kx * s), Ri[8] = (float)(c + kz * kz * v);
-      }
-      float Rn[9], tn[3];
-      for (int rr = 0; rr < 3; ++rr)
-      {
-        for (int cc = 0; cc < 3; ++cc)
-          Rn[3 * rr + cc] = Ri[3 * rr + 0] * Rc[0 + cc] + Ri[3 * rr + 1] * Rc[3 + cc] + Ri[3 * rr + 2] * Rc[6 + cc];
-        tn[rr] = (Ri[3 * rr + 0] * tc[0] + Ri[3 * rr + 1] * tc[1] + Ri[3 * rr + 2] * tc[2]) + (float)r[3 + rr];
-      }
-      memcpy(Rc, Rn, sizeof(Rc));
-      memcpy(tc, tn, sizeof(tc));
     }
   }
   memcpy(R_out, Rc, sizeof(Rc));
   memcpy(t_out, tc, sizeof(tc));
   return 0;
+}
+
+
+static int check_icp_levels(const char* who, const yakhip_icp_level* levels, int n_levels)
+{
+  int rc;
+  if (n_levels < 1 || n_levels > 16)
+    return fail(YAKHIP_EINVAL, "%s: %d pyramid levels outside [1, 16]", who, n_levels);
+  for (int l = 0; l < n_levels; ++l)
+  {
+    const yakhip_icp_level& L = levels[l];
+    if (L.iterations < 0)
+      return fail(YAKHIP_EINVAL, "%s: negative iteration count on level %d", who, l);
+    if ((rc = check_image(who, L.vcurr, L.vcurr_pitch, L.rows, L.cols, 16)) != 0 ||
+        (rc = check_image(who, L.ncurr, L.ncurr_pitch, L.rows, L.cols, 16)) != 0 ||
+        (rc = check_image(who, L.vprev, L.vprev_pitch, L.rows, L.cols, 16)) != 0 ||
+        (rc = check_image(who, L.nprev, L.nprev_pitch, L.rows, L.cols, 16)) != 0)
+      return rc;
+  }
+  return 0;
+}
+
+int yakhip_icp_estimate_sharded(yakhip_ctx* ctx, yakhip_comm* comm, const float R[9], const float t[3],
+                                const float intr[4], float dist_thres, float angle_thres, const yakhip_icp_level* levels,
+                                int n_levels, float R_out[9], float t_out[3], int* ok)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!comm || !R || !t || !intr || !levels || !R_out || !t_out || !ok)
+    return fail(YAKHIP_EINVAL, "icp_estimate_sharded: null argument");
+  if ((rc = check_icp_levels("icp_estimate_sharded", levels, n_levels)) != 0)
+    return rc;
+  *ok = 1;
+  int status = 0, iterations = 0;
+  if ((rc = launch_icp_estimate_sharded(ctx, comm, R, t, intr, dist_thres, angle_thres, levels, n_levels, R_out, t_out,
+                                        &status, &iterations)) != 0)
+    return rc;
+  if (status == 0)
+    return 0;
+  // Slow path, taken by every rank alike (they hold the same state): per linearisation the band's 33 values,
+  // their all-reduce, a wait, and the reference's host-side determinant test and SVD solve.
+  int rank = 0, world = 1;
+  yakhip_comm_info(comm, &rank, &world);
+  float* sums_dev = nullptr;
+  YAKHIP_TRY(hipMalloc((void**)&sums_dev, 33 * sizeof(float)));
+  float Rc[9], tc[3], host[33];
+  memcpy(Rc, R, sizeof(Rc));
+  memcpy(tc, t, sizeof(tc));
+  for (int l = n_levels - 1; l >= 0 && rc == 0; --l)
+  {
+    const yakhip_icp_level& L = levels[l];
+    const int r0 = (int)((long long)L.rows * rank / world), r1 = (int)((long long)L.rows * (rank + 1) / world);
+    for (int it = 0; it < L.iterations && rc == 0; ++it)
+    {
+      if ((rc = launch_icp_accumulate(ctx, Rc, tc, intr, l, dist_thres, angle_thres, (const uint8_t*)L.vcurr, L.vcurr_pitch,
+                                      (const uint8_t*)L.ncurr, L.ncurr_pitch, (const uint8_t*)L.vprev, L.vprev_pitch,
+                                      (const uint8_t*)L.nprev, L.nprev_pitch, L.rows, L.cols, nullptr, nullptr, r0, r1,
+                                      sums_dev)) != 0 ||
+          (rc = comm_allreduce(ctx, comm, sums_dev, 33, YAKHIP_SUM_F32)) != 0 ||
+          (rc = check(hipMemcpyAsync(host, sums_dev, sizeof(host), hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync")) != 0 ||
+          (rc = check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize")) != 0)
+        break;
+      if (!host_solve_step(host, Rc, tc))
+      {
+        *ok = 0;
+        l = -1;  // leave both loops with the estimate reached before the failing linearisation
+        break;
+      }
+    }
+  }
+  (void)hipFree(sums_dev);
+  memcpy(R_out, Rc, sizeof(Rc));
+  memcpy(t_out, tc, sizeof(tc));
+  return rc;
+}
+
+int yakhip_raycast_sharded(yakhip_ctx* ctx, yakhip_comm* comm, const yakhip_volume* vol, int z_own0, int z_own1,
+                           const float R[9], const float t[3], const float Rinv[9], const float intr[4],
+                           float step_factor, float gradient_delta_factor, void* points_dev, size_t points_pitch,
+                           void* depth_dev, size_t depth_pitch, void* normals_dev, size_t normals_pitch, void* keys_dev,
+                           size_t keys_pitch, int rows, int cols)
+{
+  if (!comm)
+    return fail(YAKHIP_EINVAL, "raycast_sharded: null communicator");
+  int rc = yakhip_raycast_slab(ctx, vol, z_own0, z_own1, R, t, Rinv, intr, step_factor, gradient_delta_factor, points_dev,
+                               points_pitch, depth_dev, depth_pitch, normals_dev, normals_pitch, keys_dev, keys_pitch, rows,
+                               cols);
+  if (rc != 0)
+    return rc;
+  if ((long long)rows * cols > 0x7fffffffll / 32)
+    return fail(YAKHIP_ERANGE, "raycast_sharded: image too large");
+  CompositeImages im;
+  im.points = (uint8_t*)points_dev, im.normals = (uint8_t*)normals_dev, im.depth = (uint8_t*)depth_dev;
+  im.keys = (uint8_t*)keys_dev;
+  im.points_pitch = (uint32_t)points_pitch, im.normals_pitch = (uint32_t)normals_pitch;
+  im.depth_pitch = (uint32_t)depth_pitch, im.keys_pitch = (uint32_t)keys_pitch;
+  im.rows = rows, im.cols = cols;
+  if ((rc = composite_first(ctx, comm, im, ctx->composite_capacity)) != 0)
+    return rc;
+  if ((rc = yakhip_raycast_resolve(ctx, vol, z_own0, z_own1, Rinv, gradient_delta_factor, points_dev, points_pitch,
+                                   depth_dev, depth_pitch, normals_dev, normals_pitch, keys_dev, keys_pitch, rows, cols)) != 0)
+    return rc;
+  return composite_second(ctx, comm, im, ctx->composite_capacity);
+}
+
+int yakhip_comm_status(yakhip_ctx* ctx, yakhip_comm* comm, unsigned status[2])
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!comm || !status)
+    return fail(YAKHIP_EINVAL, "comm_status: null argument");
+  return composite_status(ctx, comm, status);
 }
 
 // ---- surface extraction ------------------------------------------------------------------------

@@ -1,0 +1,548 @@
+// comm.hip -- the exchange steps of the z-slab sharded volume behind the C ABI: communicators,
+// all-reduce on the context's stream, and the composite of per-slab ray casts.  The reference has one GPU and
+// no communication at all: nothing here has a counterpart to cite; the arithmetic being
+// composited is the ray cast's (raycast.hip, yak/src/cuda/tsdf_volume.cu:288-372).
+//
+// Three transports behind one handle:
+//   rccl    ncclAllReduce on the context's stream (RCCL over xGMI), one rank per GPU, ranks being processes or
+//           threads.  librccl is opened on first use (dlopen), so the library still loads where only the HIP
+//           runtime is installed and single-GPU callers never touch it.
+//   local   ranks are threads of ONE process (each with its own context, on the same or on different GPUs);
+//           the values meet in host memory behind a barrier.  For tests on a one-GPU box (RCCL refuses two
+//           ranks on one device) and as a fallback; blocking.
+//   custom  a caller-supplied all-reduce (e.g. over torch.distributed / gloo, MPI).
+// Every transport hands every rank the same bits (the sum is formed once, in rank order, or by RCCL's ring,
+// which broadcasts one result), so ranks that solve from all-reduced values stay in lockstep.
+#include <dlfcn.h>
+#include <string.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+
+#include <rocprim/rocprim.hpp>
+
+#include "yakhip_internal.h"
+
+namespace yakhip
+{
+namespace
+{
+// ---- librccl, opened lazily ------------------------------------------------------------------------
+struct Rccl
+{
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+int rccl(Rccl** out)
+{
+  static std::mutex m;
+  static Rccl lib;
+  std::lock_guard<std::mutex> lock(m);
+  if (!lib.handle)
+  {
+    const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    for (const char* n : names)
+      if ((lib.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr)
+        break;
+    if (!lib.handle)
+      return fail(YAKHIP_ENOGPU, "librccl could not be opened: %s", dlerror());
+    lib.GetUniqueId = (decltype(lib.GetUniqueId))dlsym(lib.handle, "ncclGetUniqueId");
+    lib.CommInitRank = (decltype(lib.CommInitRank))dlsym(lib.handle, "ncclCommInitRank");
+    lib.CommDestroy = (decltype(lib.CommDestroy))dlsym(lib.handle, "ncclCommDestroy");
+    lib.AllReduce = (decltype(lib.AllReduce))dlsym(lib.handle, "ncclAllReduce");
+    lib.GetErrorString = (decltype(lib.GetErrorString))dlsym(lib.handle, "ncclGetErrorString");
+    if (!lib.GetUniqueId || !lib.CommInitRank || !lib.CommDestroy || !lib.AllReduce || !lib.GetErrorString)
+    {
+      dlclose(lib.handle);
+      lib.handle = nullptr;
+      return fail(YAKHIP_ENOGPU, "librccl lacks an expected entry point");
+    }
+  }
+  *out = &lib;
+  return 0;
+}
+
+int check_nccl(Rccl* lib, ncclResult_t r, const char* what)
+{
+  if (r == ncclSuccess)
+    return 0;
+  return fail(1000 + (int)r, "%s: %s (ncclResult %d)", what, lib->GetErrorString(r), (int)r);
+}
+
+// ---- the local transport: ranks are threads of one process ------------------------------------------
+struct LocalGroup
+{
+  std::mutex m;
+  std::condition_variable cv;
+  int world = 0, arrived = 0;
+  unsigned long long generation = 0;
+  std::vector<std::vector<uint32_t>> stage;  // one host vector per rank
+  bool broken = false;
+
+  bool barrier()
+  {
+    std::unique_lock<std::mutex> lock(m);
+    const unsigned long long g = generation;
+    if (++arrived == world)
+    {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+    }
+    else
+      cv.wait(lock, [&] { return generation != g || broken; });
+    return !broken;
+  }
+};
+}  // namespace
+}  // namespace yakhip
+
+struct yakhip_comm
+{
+  int kind;  // 0 rccl, 1 local, 2 custom
+  int rank, world;
+  ncclComm_t nccl;
+  std::shared_ptr<yakhip::LocalGroup> group;
+  yakhip_allreduce_fn fn;
+  void* user;
+  // device scratch of the ray-cast composite (allocated on first use, owned by the communicator)
+  void* scratch;
+  size_t scratch_bytes;
+};
+
+namespace yakhip
+{
+int comm_allreduce(yakhip_ctx* ctx, yakhip_comm* comm, void* buf, size_t count, int op)
+{
+  if (comm->world == 1 && comm->kind != 0)
+    return 0;
+  if (comm->kind == 0)
+  {
+    Rccl* lib = nullptr;
+    int rc = rccl(&lib);
+    if (rc != 0)
+      return rc;
+    const ncclDataType_t dt = op == YAKHIP_SUM_F32 ? ncclFloat32 : ncclInt32;
+    const ncclRedOp_t ro = op == YAKHIP_MIN_I32 ? ncclMin : ncclSum;
+    return check_nccl(lib, lib->AllReduce(buf, buf, count, dt, ro, comm->nccl, ctx->stream), "ncclAllReduce");
+  }
+  if (comm->kind == 2)
+  {
+    const int rc = comm->fn(comm->user, buf, count, op, (void*)ctx->stream);
+    return rc == 0 ? 0 : fail(rc, "custom all-reduce callback returned %d", rc);
+  }
+  // local: through host memory, summed in rank order by every rank (identical bits everywhere)
+  LocalGroup& g = *comm->group;
+  std::vector<uint32_t>& mine = g.stage[(size_t)comm->rank];
+  mine.resize(count);
+  YAKHIP_TRY(hipMemcpyAsync(mine.data(), buf, count * 4u, hipMemcpyDeviceToHost, ctx->stream));
+  YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (!g.barrier())
+    return fail(YAKHIP_EINVAL, "local communicator: a rank left the group");
+  std::vector<uint32_t> out(count);
+  for (size_t i = 0; i < count; ++i)
+  {
+    if (op == YAKHIP_SUM_F32)
+    {
+      float s = 0.f;
+      for (int r = 0; r < comm->world; ++r)
+      {
+        float v;
+        memcpy(&v, &g.stage[(size_t)r][i], 4);
+        s = r == 0 ? v : s + v;
+      }
+      memcpy(&out[i], &s, 4);
+    }
+    else if (op == YAKHIP_MIN_I32)
+    {
+      int32_t s = (int32_t)g.stage[0][i];
+      for (int r = 1; r < comm->world; ++r)
+        s = std::min(s, (int32_t)g.stage[(size_t)r][i]);
+      out[i] = (uint32_t)s;
+    }
+    else
+    {
+      uint32_t s = 0;
+      for (int r = 0; r < comm->world; ++r)
+        s += g.stage[(size_t)r][i];
+      out[i] = s;
+    }
+  }
+  if (!g.barrier())  // everybody has read every stage vector: they may be overwritten by the next call
+    return fail(YAKHIP_EINVAL, "local communicator: a rank left the group");
+  YAKHIP_TRY(hipMemcpyAsync(buf, out.data(), count * 4u, hipMemcpyHostToDevice, ctx->stream));
+  return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
+int comm_rank(const yakhip_comm* c) { return c->rank; }
+int comm_world(const yakhip_comm* c) { return c->world; }
+
+// ---- composite of the per-slab ray casts ---------------------------------------------------------
+// keys / payload images are the outputs of yakhip_raycast_slab on this rank.  Step 1: best = MIN over ranks of
+// the keys; every rank zeroes its payload where it does not hold the best key; SUM over ranks of the payload
+// bit patterns (one non-zero term: exact).  Step 2 (after yakhip_raycast_resolve on the composited images):
+// the pixels whose best key is odd -- the same list, in the same order, on every rank -- are composited once
+// more; exactly one rank (the one whose layers hold the refined point) has turned such a key even.
+constexpr int kKeyNone = 0x7fffffff;
+constexpr int kPayloadWords = 7;  // vertex xyz, normal xyz, depth
+
+__device__ __forceinline__ int32_t* key_at(const CompositeImages& im, int y, int x)
+{
+  return (int32_t*)(im.keys + (size_t)y * im.keys_pitch) + x;
+}
+
+// the fourth lane of a map pixel: 0 beside a value, the NaN itself beside a NaN (the kernels write all four lanes
+// of a pixel without a result as quiet NaN, tsdf_volume.cu:298)
+__device__ __forceinline__ uint32_t lane_w(uint32_t x) { return (x & 0x7fffffffu) > 0x7f800000u ? x : 0u; }
+
+__global__ __launch_bounds__(256) void pack_keys_kernel(CompositeImages im, int32_t* best)
+{
+  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (i < im.rows * im.cols)
+    best[i] = *key_at(im, i / im.cols, i % im.cols);
+}
+
+// payload words of pixel i, zeroed unless this rank holds the best key
+__global__ __launch_bounds__(256) void mask_pack_kernel(CompositeImages im, const int32_t* best, uint32_t* packed)
+{
+  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+  const int n = im.rows * im.cols;
+  if (i >= n)
+    return;
+  const int y = i / im.cols, x = i % im.cols;
+  const int32_t b = best[i];
+  const bool mine = b != kKeyNone && *key_at(im, y, x) == b;
+  uint32_t w[kPayloadWords] = { 0, 0, 0, 0, 0, 0, 0 };
+  if (mine)
+  {
+    if (im.points)
+    {
+      const uint4 p = ((const uint4*)(im.points + (size_t)y * im.points_pitch))[x];
+      w[0] = p.x, w[1] = p.y, w[2] = p.z;
+    }
+    const uint4 q = ((const uint4*)(im.normals + (size_t)y * im.normals_pitch))[x];
+    w[3] = q.x, w[4] = q.y, w[5] = q.z;
+    if (im.depth)
+      w[6] = ((const uint16_t*)(im.depth + (size_t)y * im.depth_pitch))[x];
+  }
+#pragma unroll
+  for (int k = 0; k < kPayloadWords; ++k)
+    packed[(size_t)k * n + i] = w[k];
+}
+
+// the composited pixel back into the images (NaN / 0 where no slab's march ended), keys <- best
+__global__ __launch_bounds__(256) void unpack_kernel(CompositeImages im, const int32_t* best, const uint32_t* packed)
+{
+  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+  const int n = im.rows * im.cols;
+  if (i >= n)
+    return;
+  const int y = i / im.cols, x = i % im.cols;
+  const int32_t b = best[i];
+  const uint32_t qnan = 0x7fc00000u;
+  uint32_t w[kPayloadWords];
+#pragma unroll
+  for (int k = 0; k < kPayloadWords; ++k)
+    w[k] = packed[(size_t)k * n + i];
+  const bool none = b == kKeyNone;
+  if (im.points)
+    ((uint4*)(im.points + (size_t)y * im.points_pitch))[x] = none ? uint4{ qnan, qnan, qnan, qnan } : uint4{ w[0], w[1], w[2], lane_w(w[0]) };
+  ((uint4*)(im.normals + (size_t)y * im.normals_pitch))[x] = none ? uint4{ qnan, qnan, qnan, qnan } : uint4{ w[3], w[4], w[5], lane_w(w[3]) };
+  if (im.depth)
+    ((uint16_t*)(im.depth + (size_t)y * im.depth_pitch))[x] = none ? (uint16_t)0 : (uint16_t)w[6];
+  *key_at(im, y, x) = b;
+}
+
+struct OddKey
+{
+  const int32_t* best;
+  __device__ bool operator()(int i) const { return best[i] != kKeyNone && (best[i] & 1); }
+};
+
+// deferred pixels after the resolve: entry j = {changed, payload} of list[j], zeros beyond the list
+__global__ __launch_bounds__(256) void gather_deferred_kernel(CompositeImages im, const int32_t* best, const int* list,
+                                                               const unsigned* count, int cap, uint32_t* entries,
+                                                               unsigned* overflow)
+{
+  const int j = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (j == 0 && *count > (unsigned)cap)
+    atomicAdd(overflow, 1u);
+  if (j >= cap)
+    return;
+  uint32_t w[kPayloadWords + 1] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  if ((unsigned)j < *count)
+  {
+    const int i = list[j], y = i / im.cols, x = i % im.cols;
+    const int32_t k = *key_at(im, y, x);
+    if ((k & 1) == 0 && k == best[i] - 1)  // this rank's resolve settled the pixel
+    {
+      w[0] = 1u;
+      if (im.points)
+      {
+        const uint4 p = ((const uint4*)(im.points + (size_t)y * im.points_pitch))[x];
+        w[1] = p.x, w[2] = p.y, w[3] = p.z;
+      }
+      const uint4 q = ((const uint4*)(im.normals + (size_t)y * im.normals_pitch))[x];
+      w[4] = q.x, w[5] = q.y, w[6] = q.z;
+      if (im.depth)
+        w[7] = ((const uint16_t*)(im.depth + (size_t)y * im.depth_pitch))[x];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kPayloadWords + 1; ++k)
+    entries[(size_t)k * cap + j] = w[k];
+}
+
+__global__ __launch_bounds__(256) void scatter_deferred_kernel(CompositeImages im, const int32_t* best, const int* list,
+                                                                const unsigned* count, int cap, const uint32_t* entries)
+{
+  const int j = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (j >= cap || (unsigned)j >= *count)
+    return;
+  if (entries[j] == 0u)
+    return;  // no slab holds the refined point (it left the volume): the pixel stays as the first step left it
+  const int i = list[j], y = i / im.cols, x = i % im.cols;
+  if (im.points)
+    ((uint4*)(im.points + (size_t)y * im.points_pitch))[x] =
+        uint4{ entries[(size_t)1 * cap + j], entries[(size_t)2 * cap + j], entries[(size_t)3 * cap + j],
+               lane_w(entries[(size_t)1 * cap + j]) };
+  ((uint4*)(im.normals + (size_t)y * im.normals_pitch))[x] =
+      uint4{ entries[(size_t)4 * cap + j], entries[(size_t)5 * cap + j], entries[(size_t)6 * cap + j],
+             lane_w(entries[(size_t)4 * cap + j]) };
+  if (im.depth)
+    ((uint16_t*)(im.depth + (size_t)y * im.depth_pitch))[x] = (uint16_t)entries[(size_t)7 * cap + j];
+  *key_at(im, y, x) = best[i] - 1;
+}
+
+// A NaN vertex with a NaN normal is how yakhip_raycast_resolve discards a hit; its payload words are NaN bit
+// patterns and travel through the integer sum like any others.
+
+struct CompositeScratch
+{
+  int32_t* best;
+  uint32_t* packed;
+  int* list;
+  unsigned* count;     // [0] list length, [1] overflow events (accumulated until read)
+  uint32_t* entries;
+  void* select_temp;
+  size_t select_bytes;
+  int cap;
+};
+
+static int composite_scratch(yakhip_ctx* ctx, yakhip_comm* comm, int n, int cap_request, CompositeScratch& s)
+{
+  s.cap = cap_request > 0 ? cap_request : (n / 64 > 4096 ? n / 64 : 4096);
+  if (s.cap > n)
+    s.cap = n;
+  size_t select_bytes = 0;
+  OddKey pred{ nullptr };
+  YAKHIP_TRY(rocprim::select(nullptr, select_bytes, rocprim::counting_iterator<int>(0), (int*)nullptr, (unsigned*)nullptr,
+                             (size_t)n, pred, ctx->stream));
+  auto up = [](size_t v) { return (v + 255u) & ~(size_t)255u; };
+  const size_t need = up((size_t)n * 4u) + up((size_t)n * 4u * kPayloadWords) + up((size_t)n * 4u) + 256u +
+                      up((size_t)s.cap * 4u * (kPayloadWords + 1)) + up(select_bytes);
+  if (comm->scratch_bytes < need)
+  {
+    if (comm->scratch)
+    {
+      YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
+      YAKHIP_TRY(hipFree(comm->scratch));
+      comm->scratch = nullptr;
+      comm->scratch_bytes = 0;
+    }
+    YAKHIP_TRY(hipMalloc(&comm->scratch, need));
+    comm->scratch_bytes = need;
+    YAKHIP_TRY(hipMemsetAsync(comm->scratch, 0, need, ctx->stream));
+  }
+  char* p = (char*)comm->scratch;
+  s.count = (unsigned*)p, p += 256;
+  s.best = (int32_t*)p, p += up((size_t)n * 4u);
+  s.packed = (uint32_t*)p, p += up((size_t)n * 4u * kPayloadWords);
+  s.list = (int*)p, p += up((size_t)n * 4u);
+  s.entries = (uint32_t*)p, p += up((size_t)s.cap * 4u * (kPayloadWords + 1));
+  s.select_temp = p;
+  s.select_bytes = select_bytes;
+  return 0;
+}
+
+int composite_first(yakhip_ctx* ctx, yakhip_comm* comm, const CompositeImages& im, int cap_request)
+{
+  const int n = im.rows * im.cols;
+  CompositeScratch s;
+  int rc = composite_scratch(ctx, comm, n, cap_request, s);
+  if (rc != 0)
+    return rc;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(pack_keys_kernel, dim3(blocks), dim3(256), 0, ctx->stream, im, s.best);
+  if ((rc = comm_allreduce(ctx, comm, s.best, (size_t)n, YAKHIP_MIN_I32)) != 0)
+    return rc;
+  hipLaunchKernelGGL(mask_pack_kernel, dim3(blocks), dim3(256), 0, ctx->stream, im, s.best, s.packed);
+  if ((rc = comm_allreduce(ctx, comm, s.packed, (size_t)n * kPayloadWords, YAKHIP_SUM_I32)) != 0)
+    return rc;
+  hipLaunchKernelGGL(unpack_kernel, dim3(blocks), dim3(256), 0, ctx->stream, im, s.best, s.packed);
+  // the pixels still to be resolved, in pixel order (the same list on every rank)
+  OddKey pred{ s.best };
+  size_t bytes = s.select_bytes;
+  YAKHIP_TRY(rocprim::select(s.select_temp, bytes, rocprim::counting_iterator<int>(0), s.list, s.count, (size_t)n, pred,
+                             ctx->stream));
+  return check(hipGetLastError(), "composite kernels");
+}
+
+int composite_second(yakhip_ctx* ctx, yakhip_comm* comm, const CompositeImages& im, int cap_request)
+{
+  const int n = im.rows * im.cols;
+  CompositeScratch s;
+  int rc = composite_scratch(ctx, comm, n, cap_request, s);
+  if (rc != 0)
+    return rc;
+  const unsigned blocks = (unsigned)((s.cap + 255) / 256);
+  hipLaunchKernelGGL(gather_deferred_kernel, dim3(blocks), dim3(256), 0, ctx->stream, im, s.best, s.list, s.count, s.cap,
+                     s.entries, s.count + 1);
+  if ((rc = comm_allreduce(ctx, comm, s.entries, (size_t)s.cap * (kPayloadWords + 1), YAKHIP_SUM_I32)) != 0)
+    return rc;
+  hipLaunchKernelGGL(scatter_deferred_kernel, dim3(blocks), dim3(256), 0, ctx->stream, im, s.best, s.list, s.count, s.cap,
+                     s.entries);
+  return check(hipGetLastError(), "composite kernels");
+}
+
+int composite_status(yakhip_ctx* ctx, yakhip_comm* comm, unsigned out[2])
+{
+  out[0] = out[1] = 0;
+  if (!comm->scratch)
+    return 0;
+  YAKHIP_TRY(hipMemcpyAsync(out, comm->scratch, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  YAKHIP_TRY(hipMemsetAsync((char*)comm->scratch + 4, 0, 4, ctx->stream));
+  return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+}  // namespace yakhip
+
+using namespace yakhip;
+
+extern "C" {
+
+int yakhip_comm_unique_id(void* id_out, size_t bytes)
+{
+  if (!id_out || bytes < sizeof(ncclUniqueId))
+    return fail(YAKHIP_EINVAL, "comm_unique_id: needs a buffer of at least %zu bytes", sizeof(ncclUniqueId));
+  Rccl* lib = nullptr;
+  int rc = rccl(&lib);
+  if (rc != 0)
+    return rc;
+  ncclUniqueId id;
+  if ((rc = check_nccl(lib, lib->GetUniqueId(&id), "ncclGetUniqueId")) != 0)
+    return rc;
+  memset(id_out, 0, bytes);
+  memcpy(id_out, &id, sizeof(id));
+  return 0;
+}
+
+static yakhip_comm* new_comm(int kind, int rank, int world)
+{
+  yakhip_comm* c = new yakhip_comm();
+  c->kind = kind, c->rank = rank, c->world = world;
+  c->nccl = nullptr, c->fn = nullptr, c->user = nullptr, c->scratch = nullptr, c->scratch_bytes = 0;
+  return c;
+}
+
+int yakhip_comm_create_rccl(yakhip_ctx* ctx, yakhip_comm** out, const void* unique_id, int world, int rank)
+{
+  if (!ctx || !out || !unique_id || world < 1 || rank < 0 || rank >= world)
+    return fail(YAKHIP_EINVAL, "comm_create_rccl: bad argument");
+  *out = nullptr;
+  YAKHIP_TRY(hipSetDevice(ctx->device));
+  Rccl* lib = nullptr;
+  int rc = rccl(&lib);
+  if (rc != 0)
+    return rc;
+  ncclUniqueId id;
+  memcpy(&id, unique_id, sizeof(id));
+  ncclComm_t nc = nullptr;
+  if ((rc = check_nccl(lib, lib->CommInitRank(&nc, world, id, rank), "ncclCommInitRank")) != 0)
+    return rc;
+  yakhip_comm* c = new_comm(0, rank, world);
+  c->nccl = nc;
+  *out = c;
+  return 0;
+}
+
+int yakhip_comm_create_local(int world, yakhip_comm** comms_out)
+{
+  if (world < 1 || !comms_out)
+    return fail(YAKHIP_EINVAL, "comm_create_local: bad argument");
+  auto g = std::make_shared<LocalGroup>();
+  g->world = world;
+  g->stage.resize((size_t)world);
+  for (int r = 0; r < world; ++r)
+  {
+    comms_out[r] = new_comm(1, r, world);
+    comms_out[r]->group = g;
+  }
+  return 0;
+}
+
+int yakhip_comm_create_custom(yakhip_comm** out, int world, int rank, yakhip_allreduce_fn fn, void* user)
+{
+  if (!out || !fn || world < 1 || rank < 0 || rank >= world)
+    return fail(YAKHIP_EINVAL, "comm_create_custom: bad argument");
+  yakhip_comm* c = new_comm(2, rank, world);
+  c->fn = fn, c->user = user;
+  *out = c;
+  return 0;
+}
+
+int yakhip_comm_destroy(yakhip_comm* comm)
+{
+  if (!comm)
+    return 0;
+  int rc = 0;
+  if (comm->scratch)
+    (void)hipFree(comm->scratch);
+  if (comm->kind == 0 && comm->nccl)
+  {
+    Rccl* lib = nullptr;
+    if ((rc = rccl(&lib)) == 0)
+      rc = check_nccl(lib, lib->CommDestroy(comm->nccl), "ncclCommDestroy");
+  }
+  if (comm->kind == 1 && comm->group)
+  {
+    std::lock_guard<std::mutex> lock(comm->group->m);
+    comm->group->broken = true;  // ranks still waiting in a barrier give up instead of hanging
+    comm->group->cv.notify_all();
+  }
+  delete comm;
+  return rc;
+}
+
+int yakhip_comm_info(const yakhip_comm* comm, int* rank, int* world)
+{
+  if (!comm)
+    return fail(YAKHIP_EINVAL, "comm_info: null communicator");
+  if (rank)
+    *rank = comm->rank;
+  if (world)
+    *world = comm->world;
+  return 0;
+}
+
+int yakhip_comm_allreduce(yakhip_ctx* ctx, yakhip_comm* comm, void* buf_dev, size_t count, int op)
+{
+  if (!ctx || !comm || !buf_dev)
+    return fail(YAKHIP_EINVAL, "comm_allreduce: null argument");
+  if (op != YAKHIP_SUM_F32 && op != YAKHIP_MIN_I32 && op != YAKHIP_SUM_I32)
+    return fail(YAKHIP_EINVAL, "comm_allreduce: unknown operation %d", op);
+  if (((uintptr_t)buf_dev & 3) != 0)
+    return fail(YAKHIP_EALIGN, "comm_allreduce: buffer not 4-byte aligned");
+  YAKHIP_TRY(hipSetDevice(ctx->device));
+  if (count == 0)
+    return 0;
+  return comm_allreduce(ctx, comm, buf_dev, count, op);
+}
+
+}  // extern "C"

@@ -330,7 +330,8 @@ __global__ __launch_bounds__(256) void icp_accumulate_kernel(const IcpParams p, 
   {
     const int pix = base + i * 256;
     live[i] = pix < n_pixels;
-    const int pc = live[i] ? pix : n_pixels - 1;  // n_pixels >= 1 (launchers); a dead lane re-reads the last pixel
+    const int pc = live[i] ? pix : (n_pixels > 0 ? n_pixels - 1 : 0);  // a dead lane re-reads the band's last pixel (an empty
+                                                                       // band of the sharded schedule: pixel (row0, 0), a valid row)
     const int yr = pc / p.cols, x = pc - yr * p.cols, y = yr + p.row0;
     s0[i] = f4_at(p.vcurr, p.vcurr_pitch, y, x);
     nc[i] = f4_at(p.ncurr, p.ncurr_pitch, y, x);
@@ -669,6 +670,106 @@ int launch_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], con
     // j == n_launches: the last launch read slot max(j - 2, 0) and (for j > 1) wrote slot j - 1
     hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(1024), 0, ctx->stream, partial[(j - 1) & 1], prev_blocks,
                        &slots[j - 1], &slots[j]);
+    YAKHIP_TRY(hipGetLastError());
+    YAKHIP_TRY(hipMemcpyAsync(host, &slots[j], sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
+    YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  for (int i = 0; i < 9; ++i)
+    R_out[i] = host->R[i];
+  for (int i = 0; i < 3; ++i)
+    t_out[i] = host->t[i];
+  *status_out = host->status;
+  *iterations_out = host->iterations;
+  return 0;
+}
+// The same schedule over the ranks of a communicator (image-space split).  Rank r walks the rows
+// [rows * r / world, rows * (r + 1) / world) of every level; per linearisation j:
+//   accumulate launch   first finishes linearisation j - 1 from the ALL-REDUCED 33 values of that linearisation
+//                       (they stand in for "one workgroup's partials": prev_blocks = 1), then accumulates its
+//                       band with the new pose into its own workgroup partials;
+//   final launch        33 waves fold those partials into 33 values;
+//   all-reduce          SUM of the 33 floats over the ranks, on the stream (132 bytes: latency only).
+// Every rank solves from the same bits, so the poses stay identical without ever being exchanged.  The 33-value
+// buffers alternate like the partials of the one-GPU schedule.  A rank whose band is empty on a coarse level
+// contributes zeros.
+int launch_icp_estimate_sharded(yakhip_ctx* ctx, yakhip_comm* comm, const float R[9], const float t[3], const float intr[4],
+                                float dist_thres, float angle_thres, const yakhip_icp_level* levels, int n_levels,
+                                float R_out[9], float t_out[3], int* status_out, int* iterations_out)
+{
+  const int world = comm_world(comm), rank = comm_rank(comm);
+  int max_blocks = 1;
+  long long n_launches = 0;
+  for (int l = 0; l < n_levels; ++l)
+  {
+    const long long n_pixels = (long long)levels[l].rows * levels[l].cols;
+    if (n_pixels > 0x7fffffffll - 2048)
+      return fail(YAKHIP_ERANGE, "icp: image too large");
+    const int nb = (int)((n_pixels + 256 * kPixelsPerLane - 1) / (256 * kPixelsPerLane));
+    if (nb > max_blocks)
+      max_blocks = nb;
+    n_launches += levels[l].iterations > 0 ? levels[l].iterations : 0;
+  }
+  if (n_launches > 100000)
+    return fail(YAKHIP_ERANGE, "icp: more than 100000 linearisations");
+  // scratch: partials | sums A | sums B | state slots 0 .. n_launches
+  const size_t partial_bytes = ((size_t)max_blocks * kValues * sizeof(float) + 255u) & ~(size_t)255u;
+  int rc = icp_scratch(ctx, partial_bytes + 512 + ((size_t)n_launches + 1) * sizeof(IcpState));
+  if (rc != 0)
+    return rc;
+  float* partial = (float*)ctx->icp_scratch;
+  float* sums[2] = { (float*)((char*)ctx->icp_scratch + partial_bytes), (float*)((char*)ctx->icp_scratch + partial_bytes + 256) };
+  IcpState* slots = (IcpState*)((char*)ctx->icp_scratch + partial_bytes + 512);
+
+  IcpState* host = (IcpState*)ctx->icp_pinned;
+  for (int i = 0; i < 9; ++i)
+    host->R[i] = R[i];
+  for (int i = 0; i < 3; ++i)
+    host->t[i] = t[i];
+  host->status = 0;
+  host->iterations = 0;
+  if (n_launches > 0)
+  {
+    YAKHIP_TRY(hipMemcpyAsync(&slots[0], host, sizeof(IcpState), hipMemcpyHostToDevice, ctx->stream));
+    int j = 0;
+    for (int l = n_levels - 1; l >= 0; --l)
+    {
+      const yakhip_icp_level& L = levels[l];
+      if (L.iterations <= 0)
+        continue;
+      IcpParams p;
+      for (int i = 0; i < 9; ++i)
+        p.R[i] = 0.f;
+      for (int i = 0; i < 3; ++i)
+        p.t[i] = 0.f;
+      const int div = 1 << l;  // projective_icp.cpp:16-22
+      p.fx = intr[0] / div, p.fy = intr[1] / div, p.cx = intr[2] / div, p.cy = intr[3] / div;
+      p.frows = (float)L.rows, p.fcols = (float)L.cols;
+      p.min_cosine = (float)cos((double)angle_thres);
+      p.dist2_thres = dist_thres * dist_thres;
+      p.vcurr = (const uint8_t*)L.vcurr, p.ncurr = (const uint8_t*)L.ncurr;
+      p.vprev = (const uint8_t*)L.vprev, p.nprev = (const uint8_t*)L.nprev;
+      p.vcurr_pitch = (uint32_t)L.vcurr_pitch, p.ncurr_pitch = (uint32_t)L.ncurr_pitch;
+      p.vprev_pitch = (uint32_t)L.vprev_pitch, p.nprev_pitch = (uint32_t)L.nprev_pitch;
+      const int r0 = (int)((long long)L.rows * rank / world), r1 = (int)((long long)L.rows * (rank + 1) / world);
+      p.rows = r1 - r0, p.cols = L.cols, p.row0 = r0;
+      // at least one workgroup even for an empty band: the launch also carries the solve of the previous
+      // linearisation and the state slot every later launch reads (an empty band accumulates nothing: rows = 0)
+      const long long band = (long long)p.rows * L.cols;
+      const int n_blocks = band > 0 ? (int)((band + 256 * kPixelsPerLane - 1) / (256 * kPixelsPerLane)) : 1;
+      for (int it = 0; it < L.iterations; ++it, ++j)
+      {
+        p.state = j == 0 ? &slots[0] : &slots[j - 1];
+        p.state_out = &slots[j];
+        p.prev_partial = j == 0 ? nullptr : sums[(j - 1) & 1];
+        p.prev_blocks = 1;
+        hipLaunchKernelGGL(icp_accumulate_kernel, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, p, partial, n_blocks);
+        hipLaunchKernelGGL(icp_final_kernel, dim3(kValues), dim3(64), 0, ctx->stream, partial, n_blocks, sums[j & 1]);
+        YAKHIP_TRY(hipGetLastError());
+        if ((rc = comm_allreduce(ctx, comm, sums[j & 1], kValues, YAKHIP_SUM_F32)) != 0)
+          return rc;
+      }
+    }
+    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(1024), 0, ctx->stream, sums[(j - 1) & 1], 1, &slots[j - 1], &slots[j]);
     YAKHIP_TRY(hipGetLastError());
     YAKHIP_TRY(hipMemcpyAsync(host, &slots[j], sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
     YAKHIP_TRY(hipStreamSynchronize(ctx->stream));

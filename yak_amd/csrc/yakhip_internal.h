@@ -38,6 +38,7 @@ struct yakhip_ctx
   void* mc_pinned;     // marching cubes: pinned host copy of the total
   void* stage[2];      // host <-> device copies: two pinned staging buffers and the events that free them
   hipEvent_t stage_done[2];
+  int composite_capacity;  // list slots of the sharded ray cast's second composite step (0 = auto)
   int kernel_timing;   // record a hipEvent pair around every integrate_kernel launch
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_events;
   size_t timing_used;
@@ -181,6 +182,24 @@ int launch_extract_cloud(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int
 int launch_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], float dist_thres,
                         float angle_thres, const yakhip_icp_level* levels, int n_levels, float R_out[9], float t_out[3],
                         int* status_out, int* iterations_out);
+
+// comm.hip: the exchange steps of the sharded volume
+struct CompositeImages
+{
+  uint8_t *points, *normals, *depth, *keys;  // points or depth may be null
+  uint32_t points_pitch, normals_pitch, depth_pitch, keys_pitch;
+  int rows, cols;
+};
+int comm_allreduce(yakhip_ctx* ctx, yakhip_comm* comm, void* buf, size_t count, int op);  // on ctx->stream
+int comm_rank(const yakhip_comm* c);
+int comm_world(const yakhip_comm* c);
+int composite_first(yakhip_ctx* ctx, yakhip_comm* comm, const CompositeImages& im, int cap_request);
+int composite_second(yakhip_ctx* ctx, yakhip_comm* comm, const CompositeImages& im, int cap_request);
+int composite_status(yakhip_ctx* ctx, yakhip_comm* comm, unsigned out[2]);
+// icp.hip: the device-resident schedule over row bands, the 33 sums of every linearisation all-reduced on the stream
+int launch_icp_estimate_sharded(yakhip_ctx* ctx, yakhip_comm* comm, const float R[9], const float t[3], const float intr[4],
+                                float dist_thres, float angle_thres, const yakhip_icp_level* levels, int n_levels,
+                                float R_out[9], float t_out[3], int* status_out, int* iterations_out);
 
 // ---- device helpers shared by kernels --------------------------------------------------------
 __device__ __forceinline__ float half_bits_to_float(uint32_t bits)
