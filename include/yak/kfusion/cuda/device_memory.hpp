@@ -10,6 +10,7 @@
 #include <yak/kfusion/exports.hpp>
 
 struct yakhip_ctx;
+struct yakhip_comm;
 
 namespace kfusion
 {
@@ -22,6 +23,19 @@ KF_EXPORTS void error(const char* error_string, const char* file, const int line
 /** The context (device + stream) the host classes submit to: one per device, created on first use.
  *  setDevice() (kinfu.hpp) selects which one is current for the calling process. */
 KF_EXPORTS yakhip_ctx* context();
+/** Makes `ctx` the context of the CALLING THREAD (nullptr: back to the device's shared one).  No counterpart in the
+ *  reference (one implicit CUDA device per process): a multi-GPU process drives each GPU from its own thread. */
+KF_EXPORTS void setContext(yakhip_ctx* ctx);
+/** The calling thread's place in a z-slab sharded volume: its communicator, rank and world size.
+ *  world == 1 (the default) is the reference's one-GPU behaviour.  TsdfVolume then holds only its own layers plus
+ *  the ray-cast halo, raycast() composites over the ranks, ProjectiveICP sums its normal equations over them. */
+struct Shard
+{
+  yakhip_comm* comm;
+  int rank, world;
+};
+KF_EXPORTS void setShard(const Shard& shard);
+KF_EXPORTS const Shard& currentShard();
 
 class KF_EXPORTS DeviceMemory
 {

@@ -49,6 +49,17 @@ public:
 
   void swap(CudaData& data);
 
+  // ---- z-slab sharding (no counterpart in the reference; world == 1 leaves everything above as it is) ----
+  /** Layers [z0, z1) of the volume this object OWNS on the calling thread's rank (cuda::currentShard()). */
+  void ownedLayers(int& z0, int& z1) const;
+  /** Layers [z0, z1) it HOLDS: the owned ones plus the ray-cast halo, integrated redundantly.  data() is this range. */
+  void heldLayers(int& z0, int& z1) const;
+  /** Device pointer of the first OWNED layer and the number of owned voxels (a sharded downloadTSDF concatenates these). */
+  const void* ownedData(size_t& voxels) const;
+  /** True if the last sharded raycast() had more pixels to settle than its list holds (include/yakhip.h,
+   *  yakhip_comm_status); KinFu then repeats that ray cast with room for all.  BLOCKING. */
+  bool raycastOverflowed();
+
   DeviceArray<Point> fetchCloud(DeviceArray<Point>& cloud_buffer) const;
   void fetchNormals(const DeviceArray<Point>& cloud, DeviceArray<Normal>& normals) const;
 
@@ -62,6 +73,10 @@ public:
   };
 
 private:
+  bool ensureSlab();  // (re)allocates (and clears) the held layers when the sharding or the halo-relevant parameters changed
+
+  int held_z0_, held_z1_;          // layers in data_ (0, dims[2] on one GPU)
+  DeviceArray2D<int> keys_;        // sharded ray cast: the march-ending pair of every pixel
   CudaData data_;
   float trunc_dist_;
   int max_weight_;

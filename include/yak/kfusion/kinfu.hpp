@@ -94,6 +94,11 @@ public:
    *  kinfu.cpp:368-377; at most 10 M points, tsdf_volume.cpp:149-155). */
   std::vector<Point> downloadCloud() const;
 
+  /** The model maps the next frame is tracked against (level 0 of the previous-frame pyramid: the latest ray cast),
+   *  rows * cols float4 each, densely packed.  No counterpart in the reference (its maps never leave the device);
+   *  used by the multi-GPU tests to compare ranks. */
+  void downloadModelMaps(void* points_out, void* normals_out) const;
+
 private:
   void allocate_buffers();
 

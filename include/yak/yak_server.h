@@ -8,6 +8,7 @@
 #define YAK_OFFLINE_FUSION_SERVER_H_
 
 #include "yak/kfusion/kinfu.hpp"
+#include "yak/kfusion/kinfu_sharded.hpp"
 #include "yak/kfusion/tsdf_container.h"
 #include "yak/mc/marching_cubes.h"
 
@@ -22,7 +23,12 @@ typedef yak::compat::EigenAffine3f Affine3f;  // stand-in with inverse(), operat
 
 namespace yak
 {
-/** Not thread safe (same contract as the reference, yak_server.h:22). */
+/** Not thread safe (same contract as the reference, yak_server.h:22).
+ *  Multi-GPU: when the environment variable YAK_HIP_DEVICES lists more than one device ("0,1,2,3,4,5,6,7") the
+ *  volume is spread over them as z-slabs (kfusion::ShardedKinFu: one rank per listed GPU, RCCL over xGMI between
+ *  them); fuse / reset / downloadTSDF / uploadTSDF keep their meaning, results are those of one GPU (bit for bit with
+ *  supplied poses).  extractMesh and display() are one-GPU features: with several devices extractMesh goes through
+ *  downloadTSDF + the device routine, display() shows rank 0's model maps. */
 class FusionServer
 {
 public:
@@ -52,7 +58,9 @@ public:
 private:
   bool step(const Eigen::Affine3f& current_pose, const Eigen::Affine3f& last_pose, const cv::Mat& depth);
 
-  kfusion::KinFu::Ptr kinfu_;
+  kfusion::KinFu::Ptr kinfu_;            // one GPU
+  kfusion::ShardedKinFu::Ptr sharded_;   // several (YAK_HIP_DEVICES); exactly one of the two is set
+  void create(const kfusion::KinFuParams& params);
   void downloadView();
 
   kfusion::cuda::Depth depthDevice_;
@@ -60,6 +68,7 @@ private:
   Eigen::Affine3f last_camera_pose_;
   kfusion::cuda::Image viewDevice_;
   std::vector<unsigned char> viewHost_;
+  int viewRows_ = 0, viewCols_ = 0;  // of viewHost_ when the view came from a sharded server
   bool display_every_frame_;
 };
 }  // namespace yak

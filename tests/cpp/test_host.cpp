@@ -2,6 +2,7 @@
 // in this image): `test_host --cpu` needs no GPU; `test_host --gpu` drives yak::FusionServer on a
 // real device and checks the downloaded volume word for word against the CPU oracle.
 #include <yak/kfusion/cuda/imgproc.hpp>
+#include <yak/kfusion/kinfu_sharded.hpp>
 #include <yak/mc/marching_cubes.h>
 #include <yak/yak_server.h>
 
@@ -13,6 +14,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -412,6 +414,158 @@ static void test_kinfu_icp_tracks_orbit()
     EXPECT(after.matrix.val[i] == p.volume_pose.matrix.val[i]);
 }
 
+// The multi-GPU host path on the one GPU of the test box: kfusion::ShardedKinFu with several ranks on device 0 (its
+// ranks are threads with their own contexts, slabs and halos, talking through the library's in-process transport;
+// on a multi-GPU node the same code runs one rank per GPU over RCCL).  Bars as tests/test_sharded_kinfu_gpu.py:
+// supplied poses -> the slabs concatenate to the one-GPU volume and every rank's model maps equal the one-GPU ray
+// cast, bit for bit, on every frame; tracking -> identical poses on all ranks, within rounding of the one-GPU track.
+static void test_sharded_kinfu_against_single()
+{
+  std::printf("ShardedKinFu (3 ranks on one GPU): supplied poses, bit for bit against KinFu\n");
+  kfusion::KinFuParams p = kfusion::KinFuParams::default_params();
+  p.volume_dims = kfusion::Vec3i::all(96);
+  p.volume_resolution = 3.f / 96.f;
+  p.volume_pose = orbit_pose(0);
+  p.use_icp = false;
+  p.update_via_sensor_motion = false;
+  const size_t voxels = (size_t)96 * 96 * 96, pixels = (size_t)p.rows * p.cols;
+  const int frames = 6;
+  {
+    kfusion::KinFu single(p);
+    kfusion::ShardedKinFu sharded(p, std::vector<int>{ 0, 0, 0 });
+    EXPECT(sharded.world() == 3);
+    std::vector<float> sp(pixels * 4), sn(pixels * 4), rp(pixels * 4), rn(pixels * 4);
+    for (int f = 0; f < frames; ++f)
+    {
+      const Affine3f pose = orbit_pose(3 * f), prev = orbit_pose(f ? 3 * (f - 1) : 0);
+      std::vector<std::uint16_t> depth = render_s2(pose, p.intr, p.rows, p.cols);
+      kfusion::cuda::Depth d;
+      d.upload(depth.data(), (size_t)p.cols * 2, p.rows, p.cols);
+      const bool a = single(Affine3f::Identity(), pose, prev, d);
+      const bool b = sharded(Affine3f::Identity(), pose, prev, depth.data(), (size_t)p.cols * 2, p.rows, p.cols);
+      EXPECT(a == b && a == (f > 0));
+      if (f == 0)
+        continue;
+      single.downloadModelMaps(sp.data(), sn.data());
+      for (int r = 0; r < 3; ++r)
+      {
+        sharded.downloadModelMaps(r, rp.data(), rn.data());
+        EXPECT(std::memcmp(sp.data(), rp.data(), pixels * 16) == 0);
+        EXPECT(std::memcmp(sn.data(), rn.data(), pixels * 16) == 0);
+      }
+    }
+    size_t hits = 0;
+    for (size_t i = 0; i < pixels; ++i)
+      hits += sp[4 * i] == sp[4 * i];
+    EXPECT(hits > 50000);
+    std::vector<std::uint32_t> one(voxels), many(voxels, 0xdeadbeefu);
+    single.tsdf().data().download(one.data());
+    sharded.downloadVolume(many.data());
+    EXPECT(std::memcmp(one.data(), many.data(), voxels * 4) == 0);
+    size_t nonzero = 0;
+    for (size_t i = 0; i < voxels; ++i)
+      nonzero += one[i] != 0;
+    EXPECT(nonzero > voxels / 20);
+  }
+
+  std::printf("ShardedKinFu (2 ranks on one GPU): tracking from depth alone, lost track\n");
+  p.use_icp = true;
+  p.update_via_sensor_motion = true;
+  {
+    kfusion::KinFu single(p);
+    kfusion::ShardedKinFu sharded(p, std::vector<int>{ 0, 0 });
+    double worst = 0, worst_diff = 0;
+    for (int f = 0; f < 8; ++f)
+    {
+      const Affine3f truth = orbit_pose(f);
+      std::vector<std::uint16_t> depth = render_s2(truth, p.intr, p.rows, p.cols);
+      kfusion::cuda::Depth d;
+      d.upload(depth.data(), (size_t)p.cols * 2, p.rows, p.cols);
+      const bool a = single(Affine3f::Identity(), Affine3f::Identity(), Affine3f::Identity(), d);
+      const bool b = sharded(Affine3f::Identity(), Affine3f::Identity(), Affine3f::Identity(), depth.data(),
+                             (size_t)p.cols * 2, p.rows, p.cols);
+      EXPECT(a == b);
+      const Affine3f e1 = single.getCameraPose(), e2 = sharded.getCameraPose();
+      for (int i = 0; i < 16; ++i)
+        worst_diff = std::max(worst_diff, (double)std::fabs(e1.matrix.val[i] - e2.matrix.val[i]));
+      worst = std::max(worst, yak::compat::norm((truth.inv() * e2).translation()));
+    }
+    std::printf("  worst position error %.2f mm, worst difference to the one-GPU track %.2e\n", worst * 1e3, worst_diff);
+    EXPECT(worst < 0.5 * 3.0 / 96 && worst_diff < 5e-4);
+    // a frame without returns: every rank reports the failure and starts over (kinfu.cpp:247-252)
+    std::vector<std::uint16_t> blank((size_t)p.rows * p.cols, 0);
+    EXPECT(!sharded(Affine3f::Identity(), Affine3f::Identity(), Affine3f::Identity(), blank.data(), (size_t)p.cols * 2, p.rows,
+                    p.cols));
+    const Affine3f after = sharded.getCameraPose();
+    for (int i = 0; i < 16; ++i)
+      EXPECT(after.matrix.val[i] == p.volume_pose.matrix.val[i]);
+    std::vector<std::uint32_t> vol((size_t)96 * 96 * 96, 1u);
+    sharded.downloadVolume(vol.data());
+    size_t nonzero = 0;
+    for (std::uint32_t w : vol)
+      nonzero += w != 0;
+    EXPECT(nonzero == 0);
+  }
+  EXPECT(kfusion::ShardedKinFu::devicesFromEnvironment().empty() || std::getenv("YAK_HIP_DEVICES"));
+}
+
+// yak::FusionServer spread over ranks by YAK_HIP_DEVICES: fuse / downloadTSDF / reset / uploadTSDF / display
+// give what the one-GPU server gives (the volume word for word: supplied poses).
+static void test_fusion_server_over_ranks()
+{
+  std::printf("FusionServer with YAK_HIP_DEVICES=0,0,0 against the one-GPU server\n");
+  kfusion::KinFuParams p = kfusion::KinFuParams::default_params();
+  p.volume_dims = kfusion::Vec3i(64, 48, 56);
+  p.volume_resolution = 3.f / 64.f;
+  p.use_icp = false;
+  p.use_pose_hints = true;
+  p.update_via_sensor_motion = false;
+  unsetenv("YAK_HIP_DEVICES");
+  yak::FusionServer one(p, Eigen::Affine3f::Identity());
+  setenv("YAK_HIP_DEVICES", "0,0,0", 1);
+  yak::FusionServer many(p, Eigen::Affine3f::Identity());
+  unsetenv("YAK_HIP_DEVICES");
+  const Affine3f poses[4] = { rot_y_translate(0.f, 1.5f, 1.2f, -2.0f), rot_y_translate(0.1f, 1.1f, 1.25f, -2.1f),
+                              rot_y_translate(-0.15f, 1.9f, 1.1f, -1.9f), rot_y_translate(0.25f, 0.8f, 1.3f, -2.2f) };
+  for (int f = 0; f < 4; ++f)
+  {
+    std::vector<std::uint16_t> depth = render(poses[f], p.intr, p.rows, p.cols);
+    const cv::Mat m(p.rows, p.cols, depth.data(), (size_t)p.cols * 2);
+    EXPECT(one.fuse(m, Eigen::Affine3f(poses[f])) == many.fuse(m, Eigen::Affine3f(poses[f])));
+  }
+  const yak::TSDFContainer a = one.downloadTSDF(), b = many.downloadTSDF();
+  EXPECT(a.size64() == b.size64() && std::memcmp(a.data(), b.data(), a.size64() * 4) == 0);
+  size_t touched = 0;
+  for (size_t i = 0; i < a.size64(); ++i)
+    touched += a.data()[i] != 0;
+  EXPECT(touched > 1000);
+  // the tracker's model view: the same pixels from rank 0's composited maps
+  one.display();
+  many.display();
+  int r1, c1, r2, c2;
+  const std::vector<unsigned char>& v1 = one.view(r1, c1);
+  const std::vector<unsigned char>& v2 = many.view(r2, c2);
+  EXPECT(r1 == r2 && c1 == c2 && v1.size() == v2.size() && !v1.empty() && v1 == v2);
+  EXPECT(many.reset());
+  const yak::TSDFContainer cleared = many.downloadTSDF();
+  size_t nz = 0;
+  for (size_t i = 0; i < cleared.size64(); ++i)
+    nz += cleared.data()[i] != 0;
+  EXPECT(nz == 0);
+  EXPECT(many.uploadTSDF(a));  // every rank takes the layers it holds, halo included
+  const yak::TSDFContainer back = many.downloadTSDF();
+  EXPECT(std::memcmp(back.data(), a.data(), a.size64() * 4) == 0);
+  EXPECT(!many.uploadTSDF(yak::TSDFContainer(8, 8, 8)));
+  // and fusion goes on from the uploaded volume like the one-GPU server's (reset() restarts the frame count on both)
+  EXPECT(one.reset() && one.uploadTSDF(a));
+  std::vector<std::uint16_t> depth = render(poses[1], p.intr, p.rows, p.cols);
+  const cv::Mat m(p.rows, p.cols, depth.data(), (size_t)p.cols * 2);
+  one.fuse(m, Eigen::Affine3f(poses[1]));
+  many.fuse(m, Eigen::Affine3f(poses[1]));
+  const yak::TSDFContainer a2 = one.downloadTSDF(), b2 = many.downloadTSDF();
+  EXPECT(std::memcmp(a2.data(), b2.data(), a2.size64() * 4) == 0);
+}
+
 // The reference's own marching-cubes test, case for case (yak/test/marching_cubes_tests.cpp:86-150):
 // a 3 x 3 x 3 volume of half(1.0), weight 1, with half(-1.0) in the middle, scale 0.01, min_weight 1,
 // clean -> 8 faces over 6 distinct vertices at the positions of the test's PLY text.
@@ -651,6 +805,11 @@ int main(int argc, char** argv)
       test_container_and_half();
       test_solve6();
       test_no_gpu_is_an_exception();
+    }
+    else if (mode == "--gpu-sharded")
+    {
+      test_sharded_kinfu_against_single();
+      test_fusion_server_over_ranks();
     }
     else
     {

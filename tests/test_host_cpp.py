@@ -39,13 +39,21 @@ def test_frontend_library_exports_reference_class_names():
                  "kfusion::cuda::DeviceMemory2D::upload(", "kfusion::cuda::getCudaEnabledDeviceCount()",
                  "yak::TSDFContainer::TSDFContainer(int, int, int)", "yak::marchingCubesCPU(",
                  "kfusion::cuda::TsdfVolume::raycast(", "kfusion::cuda::ProjectiveICP::estimateTransform(",
-                 "kfusion::cuda::depthBilateralFilter(", "kfusion::cuda::computePointNormals("]:
+                 "kfusion::cuda::depthBilateralFilter(", "kfusion::cuda::computePointNormals(",
+                 "kfusion::ShardedKinFu::ShardedKinFu(", "kfusion::ShardedKinFu::downloadVolume(",
+                 "kfusion::cuda::setShard("]:
         assert name in syms, name
 
 
 @pytest.mark.gpu
 def test_host_layer_gpu_fusion_server_matches_oracle():
     run("--gpu")
+
+
+@pytest.mark.gpu
+def test_host_layer_gpu_sharded_kinfu_matches_the_single_gpu_loop():
+    """kfusion::ShardedKinFu (C++ threads as ranks, collectives inside the C ABI) against kfusion::KinFu."""
+    run("--gpu-sharded")
 
 
 @pytest.mark.gpu

@@ -25,7 +25,7 @@ def c2v(R_v2c, t_v2c):
     return R, -R @ t_v2c.astype(np.float64)
 
 
-def run_loop(dist, track, out):
+def run_loop(dist, track, out, blank_at=None):
     from yak_amd import capi, synth
     from yak_amd.kinfu_sharded import ShardedKinFu
 
@@ -35,17 +35,22 @@ def run_loop(dist, track, out):
     maps, poses = [], []
     for f in range(FRAMES):
         depth, R_v2c, t_v2c = synth.scene_s2(3 * f)
+        if f == blank_at:
+            depth = np.zeros_like(depth)  # a frame without a single return: ICP has nothing to hold on to
         d = torch.from_numpy(depth.view(np.int16)).cuda()
         true_pose = c2v(R_v2c, t_v2c)
         fused = kf(d, pose=None if track else true_pose, first_pose=true_pose)
-        assert fused == (f > 0)
+        if blank_at is None:
+            assert fused == (f > 0)
+        out.setdefault("fused", []).append(bool(fused))
+        out.setdefault("frame_counter", []).append(int(kf.frame))
         poses.append((kf.pose_R.copy(), kf.pose_t.copy(), true_pose[1]))
         maps.append((kf.prv_p[0].cpu().numpy().copy(), kf.prv_n[0].cpu().numpy().copy()))
     out.update(volume=kf.own_layers().cpu().numpy().copy(), own=kf.own, maps=maps, poses=poses)
     ctx.close()
 
 
-def _worker(rank, world, port, track, path):
+def _worker(rank, world, port, track, path, blank_at=None):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
 
@@ -54,15 +59,16 @@ def _worker(rank, world, port, track, path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         out = {}
-        run_loop(dist, track, out)
-        np.savez(path % rank, volume=out["volume"], own=np.int64(out["own"]),
+        run_loop(dist, track, out, blank_at)
+        np.savez(path % rank, volume=out["volume"], own=np.int64(out["own"]), fused=np.int64(out["fused"]),
+                 frame_counter=np.int64(out["frame_counter"]),
                  points=np.stack([p for p, _ in out["maps"]]), normals=np.stack([n for _, n in out["maps"]]),
                  pose_R=np.stack([r for r, _, _ in out["poses"]]), pose_t=np.stack([t for _, t, _ in out["poses"]]))
     finally:
         dist.destroy_process_group()
 
 
-def spawn(world, track, tmp_path):
+def spawn(world, track, tmp_path, blank_at=None):
     import torch.multiprocessing as mp
 
     s = socket.socket()
@@ -70,7 +76,7 @@ def spawn(world, track, tmp_path):
     port = s.getsockname()[1]
     s.close()
     path = str(tmp_path / ("w%d_t%d_r%%d.npz" % (world, int(track))))
-    mp.spawn(_worker, args=(world, port, track, path), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, track, path, blank_at), nprocs=world, join=True)
     return [np.load(path % r) for r in range(world)]
 
 
@@ -101,3 +107,23 @@ def test_sharded_loop_tracks_like_the_single_gpu_loop(tmp_path):
         assert np.abs(ranks[0]["pose_t"][f] - t1).max() < 2e-4                  # metres: rounding of the sums only
         assert np.abs(ranks[0]["pose_R"][f] - R1).max() < 2e-4
         assert np.linalg.norm(ranks[0]["pose_t"][f] - t_true) < 0.5 * dims_vs  # and both stay on the orbit
+
+
+def test_lost_track_resets_every_rank_like_the_single_gpu_loop(tmp_path):
+    """kinfu.cpp:247-252: when ICP fails the volume is cleared, the pose list reset and the frame counter set to 0,
+    so the next frame seeds the model again.  A frame without returns in mid-sequence: the sharded loop and the
+    one-rank loop report the same frames as fused, count frames alike, and end with the same volume."""
+    blank = 3
+    single = {}
+    run_loop(None, True, single, blank_at=blank)
+    assert single["fused"][blank] is False and single["frame_counter"][blank] == 0
+    assert single["fused"][blank + 1] is False and single["frame_counter"][blank + 1] == 1   # the re-seeding frame
+    assert single["fused"][blank + 2] is True
+    ranks = spawn(2, True, tmp_path, blank_at=blank)
+    for r in ranks:
+        assert list(r["fused"]) == [int(v) for v in single["fused"]]
+        assert list(r["frame_counter"]) == single["frame_counter"]
+    whole = np.concatenate([r["volume"] for r in ranks])
+    # after the reset both loops restart from the same first pose; tracking then differs by rounding only
+    same = np.count_nonzero((whole >> 16) == (single["volume"] >> 16)) / whole.size
+    assert same > 0.999, same

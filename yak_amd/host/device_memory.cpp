@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 
@@ -32,7 +33,11 @@ void error(const char* error_string, const char* file, const int line, const cha
 
 namespace
 {
-int g_device = 0;
+// per thread: a multi-GPU process drives every GPU (rank) from its own thread (kfusion::ShardedKinFu)
+thread_local int g_device = 0;
+thread_local yakhip_ctx* g_context = nullptr;  // setContext(): this thread's own context instead of the device's shared one
+thread_local Shard g_shard = { nullptr, 0, 1 };
+std::mutex g_contexts_mutex;
 std::map<int, yakhip_ctx*>& contexts()
 {
   static std::map<int, yakhip_ctx*> m;
@@ -40,8 +45,15 @@ std::map<int, yakhip_ctx*>& contexts()
 }
 }  // namespace
 
+void setContext(yakhip_ctx* ctx) { g_context = ctx; }
+void setShard(const Shard& shard) { g_shard = shard; }
+const Shard& currentShard() { return g_shard; }
+
 yakhip_ctx* context()
 {
+  if (g_context)
+    return g_context;
+  std::lock_guard<std::mutex> lock(g_contexts_mutex);
   auto& m = contexts();
   auto it = m.find(g_device);
   if (it != m.end())

@@ -2,8 +2,17 @@
 #include <yak/kfusion/cuda/imgproc.hpp>
 #include <yak/kfusion/kinfu.hpp>
 
+#include <yakhip.h>
+
 #include <iostream>
 #include <stdexcept>
+
+#define YAK_SET_OPTION(key, value)                                                       \
+  do                                                                                     \
+  {                                                                                      \
+    if (yakhip_ctx_set_option(cuda::context(), key, value) != 0)                         \
+      cuda::error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_ctx_set_option");     \
+  } while (0)
 
 namespace kfusion
 {
@@ -163,6 +172,14 @@ std::vector<Point> KinFu::downloadCloud() const
   return result;
 }
 
+void KinFu::downloadModelMaps(void* points_out, void* normals_out) const
+{
+  const cuda::Cloud& p = prev_.points_pyr[0];
+  const cuda::Normals& n = prev_.normals_pyr[0];
+  p.download(points_out, (size_t)p.cols() * sizeof(Point));
+  n.download(normals_out, (size_t)n.cols() * sizeof(Normal));
+}
+
 // kinfu.cpp:162-309
 bool KinFu::operator()(const Affine3f& inputCameraMotion, const Affine3f& currentCameraPose,
                        const Affine3f& previousCameraPose, const cuda::Depth& depth, const cuda::Image& /*image*/)
@@ -233,6 +250,16 @@ bool KinFu::operator()(const Affine3f& inputCameraMotion, const Affine3f& curren
     cuda::resizePointsNormals(prev_.points_pyr[i - 1], prev_.normals_pyr[i - 1], prev_.points_pyr[i],
                               prev_.normals_pyr[i]);
   cuda::waitAllDefaultStream();
+  if (volume_->raycastOverflowed())  // sharded volume only: more pixels to settle than the composite's list holds
+  {
+    YAK_SET_OPTION("composite_capacity", p.rows * p.cols);
+    volume_->raycast(poses_.back(), p.intr, prev_.points_pyr[0], prev_.normals_pyr[0]);
+    for (int i = 1; i < LEVELS; ++i)
+      cuda::resizePointsNormals(prev_.points_pyr[i - 1], prev_.normals_pyr[i - 1], prev_.points_pyr[i],
+                                prev_.normals_pyr[i]);
+    cuda::waitAllDefaultStream();
+    YAK_SET_OPTION("composite_capacity", 0);
+  }
   return ++frame_counter_, true;
 }
 }  // namespace kfusion

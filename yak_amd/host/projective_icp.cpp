@@ -75,7 +75,16 @@ bool ProjectiveICP::estimateTransform(const Affine3f& affine, Affine3f& correcte
   const float tf[3] = { t[0], t[1], t[2] }, in[4] = { intr.fx, intr.fy, intr.cx, intr.cy };
   float Ro[9], to[3];
   int ok = 0;
-  if (yakhip_icp_estimate(context(), R.val, tf, in, dist_thres_, angle_thres_, levels.data(), LEVELS, Ro, to, &ok) != 0)
+  const Shard& sh = currentShard();
+  if (sh.world > 1)
+  {
+    // every rank its band of rows, the 33 sums of each linearisation all-reduced on the stream, the same solve
+    // from the same bits on every rank (include/yakhip.h)
+    if (yakhip_icp_estimate_sharded(context(), sh.comm, R.val, tf, in, dist_thres_, angle_thres_, levels.data(), LEVELS, Ro,
+                                    to, &ok) != 0)
+      error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_icp_estimate_sharded");
+  }
+  else if (yakhip_icp_estimate(context(), R.val, tf, in, dist_thres_, angle_thres_, levels.data(), LEVELS, Ro, to, &ok) != 0)
     error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_icp_estimate");
   Mat3f Rm;
   for (int i = 0; i < 9; ++i)

@@ -95,7 +95,9 @@ TsdfVolume::Entry::half TsdfVolume::Entry::float2half(float value)
 
 // reference tsdf_volume.cpp:19-30: defaults trunc 0.03, max weight 128, 3 m cube, identity pose
 TsdfVolume::TsdfVolume(const Vec3i& dims)
-  : data_()
+  : held_z0_(0)
+  , held_z1_(0)
+  , data_()
   , trunc_dist_(0.03f)
   , max_weight_(128)
   , dims_(dims)
@@ -112,10 +114,75 @@ TsdfVolume::~TsdfVolume() {}
 void TsdfVolume::create(const Vec3i& dims)
 {
   dims_ = dims;
-  const size_t voxels = (size_t)dims_[0] * (size_t)dims_[1] * (size_t)dims_[2];
-  data_.create(voxels * sizeof(int));
+  held_z0_ = held_z1_ = 0;  // forces the allocation in ensureSlab()
   setTruncDist(trunc_dist_);
   clear();
+}
+
+// z-slab sharding: rank r of w owns layers [Z r / w, Z (r + 1) / w) and holds the ray-cast halo around them
+// (yakhip_raycast_halo: it depends on the truncation distance, the voxel size and the two ray-cast factors, which
+// the reference's setters may change after create(): every entry point passes through here first).
+void TsdfVolume::ownedLayers(int& z0, int& z1) const
+{
+  const Shard& sh = currentShard();
+  z0 = (int)((long long)dims_[2] * sh.rank / sh.world);
+  z1 = (int)((long long)dims_[2] * (sh.rank + 1) / sh.world);
+}
+void TsdfVolume::heldLayers(int& z0, int& z1) const
+{
+  ownedLayers(z0, z1);
+  if (currentShard().world == 1)
+    return;
+  yakhip_volume probe;
+  probe.data = (void*)256;  // not looked at
+  const Vec3f vsz = getVoxelSize();
+  for (int i = 0; i < 3; ++i)
+  {
+    probe.dims[i] = dims_[i];
+    probe.voxel_size[i] = vsz[i];
+  }
+  probe.z0 = 0, probe.z1 = dims_[2], probe.trunc_dist = trunc_dist_, probe.max_weight = max_weight_;
+  int halo = 0;
+  YAK_CHECK(yakhip_raycast_halo(&probe, raycast_step_factor_, gradient_delta_factor_, &halo));
+  z0 = std::max(0, z0 - halo);
+  z1 = std::min(dims_[2], z1 + halo);
+}
+bool TsdfVolume::ensureSlab()
+{
+  int z0, z1;
+  heldLayers(z0, z1);
+  if (z0 == held_z0_ && z1 == held_z1_ && !data_.empty())
+    return false;
+  held_z0_ = z0, held_z1_ = z1;
+  data_.create((size_t)dims_[0] * (size_t)dims_[1] * (size_t)(z1 - z0) * sizeof(int));
+  yakhip_volume v;
+  v.data = data_.ptr<void>();
+  const Vec3f vsz = getVoxelSize();
+  for (int i = 0; i < 3; ++i)
+  {
+    v.dims[i] = dims_[i];
+    v.voxel_size[i] = vsz[i];
+  }
+  v.z0 = z0, v.z1 = z1, v.trunc_dist = trunc_dist_, v.max_weight = max_weight_;
+  YAK_CHECK(yakhip_clear_volume(context(), &v));
+  return true;
+}
+const void* TsdfVolume::ownedData(size_t& voxels) const
+{
+  int o0, o1;
+  ownedLayers(o0, o1);
+  const size_t plane = (size_t)dims_[0] * (size_t)dims_[1];
+  voxels = plane * (size_t)(o1 - o0);
+  return data_.ptr<unsigned>() + plane * (size_t)(o0 - held_z0_);
+}
+bool TsdfVolume::raycastOverflowed()
+{
+  const Shard& sh = currentShard();
+  if (sh.world == 1 || !sh.comm)
+    return false;
+  unsigned status[2] = { 0, 0 };
+  YAK_CHECK(yakhip_comm_status(context(), sh.comm, status));
+  return status[1] != 0;
 }
 Vec3i TsdfVolume::getDims() const { return dims_; }
 Vec3f TsdfVolume::getVoxelSize() const  // :45-48
@@ -154,7 +221,7 @@ void TsdfVolume::applyAffine(const Affine3f& affine) { pose_ = affine * pose_; }
 
 namespace
 {
-yakhip_volume make_view(void* data, const Vec3i& dims, const Vec3f& vsz, float trunc, int max_weight)
+yakhip_volume make_view(void* data, const Vec3i& dims, const Vec3f& vsz, float trunc, int max_weight, int z0 = 0, int z1 = -1)
 {
   yakhip_volume v;
   v.data = data;
@@ -163,8 +230,8 @@ yakhip_volume make_view(void* data, const Vec3i& dims, const Vec3f& vsz, float t
     v.dims[i] = dims[i];
     v.voxel_size[i] = vsz[i];
   }
-  v.z0 = 0;
-  v.z1 = dims[2];
+  v.z0 = z0;
+  v.z1 = z1 < 0 ? dims[2] : z1;
   v.trunc_dist = trunc;
   v.max_weight = max_weight;
   return v;
@@ -173,7 +240,9 @@ yakhip_volume make_view(void* data, const Vec3i& dims, const Vec3f& vsz, float t
 
 void TsdfVolume::clear()  // :80-87
 {
-  yakhip_volume v = make_view(data_.ptr<void>(), dims_, getVoxelSize(), trunc_dist_, max_weight_);
+  if (ensureSlab())
+    return;  // freshly allocated layers are cleared
+  yakhip_volume v = make_view(data_.ptr<void>(), dims_, getVoxelSize(), trunc_dist_, max_weight_, held_z0_, held_z1_);
   YAK_CHECK(yakhip_clear_volume(context(), &v));
 }
 
@@ -187,7 +256,9 @@ void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_motion_tfo
   const float Rf[9] = { R.val[0], R.val[1], R.val[2], R.val[3], R.val[4], R.val[5], R.val[6], R.val[7], R.val[8] };
   const float tf[3] = { t[0], t[1], t[2] };
   const float in[4] = { intr.fx, intr.fy, intr.cx, intr.cy };
-  yakhip_volume v = make_view(data_.ptr<void>(), dims_, getVoxelSize(), trunc_dist_, max_weight_);
+  ensureSlab();
+  // a rank integrates every layer it holds: its own and, redundantly, the halo (nothing is exchanged)
+  yakhip_volume v = make_view(data_.ptr<void>(), dims_, getVoxelSize(), trunc_dist_, max_weight_, held_z0_, held_z1_);
   YAK_CHECK(yakhip_integrate(context(), &v, dists.ptr(), dists.step(), dists.rows(), dists.cols(), Rf, tf, in));
   YAK_CHECK(yakhip_ctx_synchronize(context()));
 }
@@ -222,7 +293,19 @@ void TsdfVolume::raycast(const Affine3f& camera_pose, const Intr& intr, Depth& d
 {
   const RaycastPose rp = raycast_pose(pose_, camera_pose);
   const float in[4] = { intr.fx, intr.fy, intr.cx, intr.cy };
-  yakhip_volume v = make_view(data_.ptr<void>(), dims_, getVoxelSize(), trunc_dist_, max_weight_);
+  ensureSlab();
+  yakhip_volume v = make_view(data_.ptr<void>(), dims_, getVoxelSize(), trunc_dist_, max_weight_, held_z0_, held_z1_);
+  const Shard& sh = currentShard();
+  if (sh.world > 1)
+  {
+    int o0, o1;
+    ownedLayers(o0, o1);
+    keys_.create(depth.rows(), depth.cols());
+    YAK_CHECK(yakhip_raycast_sharded(context(), sh.comm, &v, o0, o1, rp.R, rp.t, rp.Rinv, in, raycast_step_factor_,
+                                     gradient_delta_factor_, nullptr, 0, depth.ptr(), depth.step(), normals.ptr(),
+                                     normals.step(), keys_.ptr(), keys_.step(), depth.rows(), depth.cols()));
+    return;
+  }
   YAK_CHECK(yakhip_raycast_depth(context(), &v, rp.R, rp.t, rp.Rinv, in, raycast_step_factor_, gradient_delta_factor_,
                                  depth.ptr(), depth.step(), normals.ptr(), normals.step(), depth.rows(), depth.cols()));
 }
@@ -231,7 +314,21 @@ void TsdfVolume::raycast(const Affine3f& camera_pose, const Intr& intr, Cloud& p
 {
   const RaycastPose rp = raycast_pose(pose_, camera_pose);
   const float in[4] = { intr.fx, intr.fy, intr.cx, intr.cy };
-  yakhip_volume v = make_view(data_.ptr<void>(), dims_, getVoxelSize(), trunc_dist_, max_weight_);
+  ensureSlab();
+  yakhip_volume v = make_view(data_.ptr<void>(), dims_, getVoxelSize(), trunc_dist_, max_weight_, held_z0_, held_z1_);
+  const Shard& sh = currentShard();
+  if (sh.world > 1)
+  {
+    // slab march, composite over the ranks, resolve, composite of the settled pixels: one stream-ordered call
+    // after which every rank holds the whole-volume maps, bit for bit (include/yakhip.h)
+    int o0, o1;
+    ownedLayers(o0, o1);
+    keys_.create(points.rows(), points.cols());
+    YAK_CHECK(yakhip_raycast_sharded(context(), sh.comm, &v, o0, o1, rp.R, rp.t, rp.Rinv, in, raycast_step_factor_,
+                                     gradient_delta_factor_, points.ptr(), points.step(), nullptr, 0, normals.ptr(),
+                                     normals.step(), keys_.ptr(), keys_.step(), points.rows(), points.cols()));
+    return;
+  }
   YAK_CHECK(yakhip_raycast_points(context(), &v, rp.R, rp.t, rp.Rinv, in, raycast_step_factor_, gradient_delta_factor_,
                                   points.ptr(), points.step(), normals.ptr(), normals.step(), points.rows(),
                                   points.cols()));
@@ -249,7 +346,8 @@ DeviceArray<Point> TsdfVolume::fetchCloud(DeviceArray<Point>& cloud_buffer) cons
 
   const Mat3f R = pose_.rotation();
   const Vec3f t = pose_.translation();
-  yakhip_volume v = make_view(const_cast<void*>(data_.ptr<void>()), dims_, getVoxelSize(), trunc_dist_, max_weight_);
+  yakhip_volume v = make_view(const_cast<void*>(data_.ptr<void>()), dims_, getVoxelSize(), trunc_dist_, max_weight_, held_z0_,
+                              held_z1_);
   unsigned long long n = 0;
   YAK_CHECK(yakhip_extract_cloud(context(), &v, R.val, t.val, cloud_buffer.ptr(), cloud_buffer.size(), &n));
   const size_t size = n < cloud_buffer.size() ? (size_t)n : cloud_buffer.size();

@@ -7,13 +7,17 @@ yak_amd/host/kinfu.cpp does for one GPU; what changes with more than one rank:
     redundantly: integrate is a per-voxel function of the frame, so nothing is exchanged);
   * pre-processing of the depth frame (bilateral, pyramid, point / normal maps) is replicated -- it is
     image-space and costs 0.08 ms;
-  * ICP: every rank accumulates the sums of its band of rows, the 33 values are all-reduced, every rank
-    solves the same 6 x 6 system (projective_icp.cpp:206-229) and so holds the same pose;
-  * raycast: yakhip_raycast_slab -> composite (two all-reduces) -> yakhip_raycast_resolve -> the few
-    deferred pixels once more; every rank ends up with the whole model maps.
+  * ICP: yakhip_icp_estimate_sharded -- every rank accumulates the sums of its band of rows, the 33 values
+    of each linearisation are all-reduced on the stream, every rank solves the same 6 x 6 system on the device
+    (projective_icp.cpp:206-229) and so holds the same pose; the host waits once per frame;
+  * raycast: yakhip_raycast_sharded -- slab march, composite (two all-reduces), resolve, the few deferred
+    pixels once more (a third); every rank ends up with the whole model maps;
+  * a lost track resets volume, pose and frame counter on every rank alike (kinfu.cpp:247-252).
 
-This is host-side plumbing over the C ABI (yak_amd/capi.py) and torch.distributed; all arithmetic on
-images and voxels happens in libyakhip.  The reference has no multi-GPU mode: there is nothing to cite
+This is host-side plumbing over the C ABI (yak_amd/capi.py); all arithmetic on images and voxels AND the
+collectives of the frame loop happen in libyakhip (RCCL when torch.distributed runs over nccl; over gloo the
+library calls back into make_comm's host-staged all-reduce).  The C++ counterpart is kfusion::ShardedKinFu
+(yak_amd/host/kinfu_sharded.cpp).  The reference has no multi-GPU mode: there is nothing to cite
 for the collectives.
 """
 import math
@@ -21,39 +25,16 @@ import math
 import numpy as np
 
 from . import capi
-from .shard import composite_raycast, held_range, row_range, slab_range
+from .shard import held_range, slab_range
 
 LEVELS = 3                     # ProjectiveICP::MAX_PYRAMID_LEVELS - 1 used levels, kinfu.cpp:10-48 (iters 10, 5, 4, 0)
 ITERATIONS = (10, 5, 4)        # on levels 0, 1, 2 as ProjectiveICP::setIterationsNum stores them (projective_icp.cpp:87-96)
 
 
-def rodrigues(r):
-    """cv::Affine3f(rvec, tvec)'s rotation, projective_icp.cpp:225."""
-    th = float(np.linalg.norm(r))
-    if th < 1e-12:
-        return np.eye(3)
-    k = np.asarray(r, dtype=np.float64) / th
-    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
-    return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * (K @ K)
-
-
-def normal_equations(sums):
-    """StreamHelper::get, projective_icp.cpp:42-61: 27 sums -> symmetric A (6 x 6), b (6)."""
-    A, b, k = np.zeros((6, 6)), np.zeros(6), 0
-    for i in range(6):
-        for j in range(i, 7):
-            if j == 6:
-                b[i] = sums[k]
-            else:
-                A[i, j] = A[j, i] = sums[k]
-            k += 1
-    return A, b
-
-
 class ShardedKinFu:
     def __init__(self, ctx, dist, dims, voxel_size, trunc_dist, max_weight, intr, rows, cols, device="cuda",
                  bilateral=(7, 4.5, 0.04), icp_dist_thres=0.1, icp_angle_thres=math.radians(30.0), step_factor=0.75,
-                 gradient_delta_factor=0.5):
+                 gradient_delta_factor=0.5, comm=None):
         import torch
 
         self.torch, self.ctx, self.dist = torch, ctx, dist
@@ -81,7 +62,8 @@ class ShardedKinFu:
         self.cur_p, self.cur_n = [f4(r, c) for r, c in lv], [f4(r, c) for r, c in lv]
         self.prv_p, self.prv_n = [f4(r, c) for r, c in lv], [f4(r, c) for r, c in lv]
         self.keys = torch.zeros((rows, cols), dtype=torch.int32, device=device)
-        self.sums = torch.zeros(33, dtype=torch.float32, device=device)
+        self.comm = comm if comm is not None else make_comm(ctx, dist)
+        self.first_R, self.first_t = np.eye(3), np.zeros(3)
         self.pose_R, self.pose_t = np.eye(3), np.zeros(3)          # camera -> volume
         self.frame = 0
 
@@ -100,27 +82,15 @@ class ShardedKinFu:
                                        self.cur_p[l].data_ptr(), (cols >> l) * 16, self.cur_n[l].data_ptr(), (cols >> l) * 16)
 
     def _estimate_motion(self):
-        """ProjectiveICP::estimateTransform, projective_icp.cpp:175-232, with the sums of each linearisation
-        gathered over the ranks.  Returns (ok, R, t): current -> previous camera."""
-        R, t = np.eye(3), np.zeros(3)
-        for l in reversed(range(LEVELS)):
-            r_, c_ = self.rows >> l, self.cols >> l
-            r0, r1 = row_range(r_, self.world, self.rank)
-            for _ in range(ITERATIONS[l]):
-                self.ctx.icp_accumulate_rows(np.float32(R).reshape(-1), np.float32(t), self.intr, l, self.dist_thres,
-                                             self.angle_thres, self.cur_p[l].data_ptr(), c_ * 16, self.cur_n[l].data_ptr(),
-                                             c_ * 16, self.prv_p[l].data_ptr(), c_ * 16, self.prv_n[l].data_ptr(), c_ * 16,
-                                             r_, c_, r0, r1, self.sums.data_ptr())
-                self.ctx.synchronize()
-                total = _all_reduce(self.dist, self.sums, "sum").cpu().numpy().astype(np.float64)
-                A, b = normal_equations(total[:27])
-                det = np.linalg.det(A)
-                if not (abs(det) >= 1e-15):                         # projective_icp.cpp:213 (NaN fails too)
-                    return False, R, t
-                x = np.linalg.solve(A, b)
-                Ri = rodrigues(x[:3])
-                R, t = Ri @ R, Ri @ t + x[3:]                       # :225-227  Tinc * (R, t)
-        return True, R, t
+        """ProjectiveICP::estimateTransform, projective_icp.cpp:175-232, over the ranks: yakhip_icp_estimate_sharded
+        runs the whole coarse-to-fine schedule on the device -- every rank its band of rows, the 33 sums of each
+        linearisation all-reduced on the stream -- and the host waits once.  Returns (ok, R, t): current ->
+        previous camera, the same bits on every rank."""
+        levels = [(self.cur_p[l].data_ptr(), self.cur_n[l].data_ptr(), self.prv_p[l].data_ptr(), self.prv_n[l].data_ptr(),
+                   (self.cols >> l) * 16, self.rows >> l, self.cols >> l, ITERATIONS[l]) for l in range(LEVELS)]
+        R, t, ok = self.ctx.icp_estimate_sharded(self.comm, np.eye(3).reshape(-1), np.zeros(3), self.intr, self.dist_thres,
+                                                 self.angle_thres, levels)
+        return ok, np.float64(R).reshape(3, 3), np.float64(t)
 
     def _integrate(self):
         Rv = self.pose_R.T
@@ -137,23 +107,11 @@ class ShardedKinFu:
             ctx.raycast_points(self.desc, R, t, Rinv, self.intr, self.prv_p[0].data_ptr(), cols * 16, self.prv_n[0].data_ptr(),
                                cols * 16, rows, cols, self.step_factor, self.gdf)
         else:
-            ctx.raycast_slab(self.desc, self.own[0], self.own[1], R, t, Rinv, self.intr, self.keys.data_ptr(), cols * 4,
-                             self.prv_n[0].data_ptr(), cols * 16, rows, cols, points_ptr=self.prv_p[0].data_ptr(),
-                             points_pitch=cols * 16, step_factor=self.step_factor, gradient_delta_factor=self.gdf)
-            ctx.synchronize()
-
-            def resolve(keys, images):
-                ctx.raycast_resolve(self.desc, self.own[0], self.own[1], Rinv, keys.data_ptr(), cols * 4, images[1].data_ptr(),
-                                    cols * 16, rows, cols, points_ptr=images[0].data_ptr(), points_pitch=cols * 16,
-                                    gradient_delta_factor=self.gdf)
-                ctx.synchronize()
-
-            (p0, n0), best, left = composite_raycast(self.dist, self.keys, [self.prv_p[0], self.prv_n[0]],
-                                                     [float("nan"), float("nan")], resolve=resolve,
-                                                     all_reduce=_all_reduce)
-            assert left == 0
-            self.prv_p[0].copy_(p0)
-            self.prv_n[0].copy_(n0)
+            # slab march, composite (MIN over the keys, SUM over the winners' payload), resolve, composite of the
+            # settled pixels: one call, enqueued on the stream, nothing waited for (include/yakhip.h)
+            ctx.raycast_sharded(self.comm, self.desc, self.own[0], self.own[1], R, t, Rinv, self.intr, self.keys.data_ptr(),
+                                cols * 4, self.prv_n[0].data_ptr(), cols * 16, rows, cols, points_ptr=self.prv_p[0].data_ptr(),
+                                points_pitch=cols * 16, step_factor=self.step_factor, gradient_delta_factor=self.gdf)
         for l in range(1, LEVELS):
             ctx.resize_points_normals(self.prv_p[l - 1].data_ptr(), (cols >> (l - 1)) * 16, self.prv_n[l - 1].data_ptr(),
                                       (cols >> (l - 1)) * 16, rows >> (l - 1), cols >> (l - 1), self.prv_p[l].data_ptr(),
@@ -168,6 +126,7 @@ class ShardedKinFu:
         if self.frame == 0:
             if first_pose is not None:
                 self.pose_R, self.pose_t = np.asarray(first_pose[0], dtype=np.float64), np.asarray(first_pose[1], dtype=np.float64)
+                self.first_R, self.first_t = self.pose_R.copy(), self.pose_t.copy()
             self._integrate()
             # kinfu.cpp:196-198 swaps the frame's own maps in as the first model maps
             self.cur_p, self.prv_p = self.prv_p, self.cur_p
@@ -178,6 +137,12 @@ class ShardedKinFu:
         if pose is None:
             ok, R, t = self._estimate_motion()
             if not ok:
+                # kinfu.cpp:247-252: resetVolume() + resetPose() -- the volume is cleared, the frame counter goes
+                # to 0 and the next frame seeds the model again (every rank takes this branch alike)
+                self.ctx.clear_volume(self.desc)
+                self.pose_R, self.pose_t = self.first_R.copy(), self.first_t.copy()
+                self.ctx.synchronize()
+                self.frame = 0
                 return False
             self.pose_R, self.pose_t = self.pose_R @ R, self.pose_R @ t + self.pose_t     # kinfu.cpp:256-268
         else:
@@ -185,6 +150,12 @@ class ShardedKinFu:
         self._integrate()
         self._raycast_model()
         self.ctx.synchronize()
+        if self.world > 1 and self.ctx.comm_status(self.comm)[1]:
+            # more pixels to settle than the composite's list holds (include/yakhip.h): once more with room for all
+            self.ctx.set_option("composite_capacity", self.rows * self.cols)
+            self._raycast_model()
+            self.ctx.synchronize()
+            self.ctx.set_option("composite_capacity", 0)
         self.frame += 1
         return True
 
@@ -195,15 +166,27 @@ class ShardedKinFu:
         return self.volume[a:a + (self.own[1] - self.own[0]) * plane]
 
 
-def _all_reduce(dist, tensor, op):
-    """all_reduce that also works for device tensors over a CPU-only backend (gloo in the tests)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return tensor
-    red = {"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN}[op]
-    if tensor.is_cuda and dist.get_backend() == "gloo":
-        host = tensor.cpu()
-        dist.all_reduce(host, op=red)
-        tensor.copy_(host)
-    else:
-        dist.all_reduce(tensor, op=red)
-    return tensor
+def make_comm(ctx, dist):
+    """The yakhip communicator of this process's rank: RCCL when torch.distributed runs over nccl (the unique id
+    travels through torch.distributed once, the collectives of the frame loop are then the library's own, on its
+    stream), else a caller-supplied all-reduce that stages the values through the host for gloo."""
+    import torch
+
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    if world == 1:
+        return capi.Comm.local(1)[0]
+    rank = dist.get_rank()
+    if dist.get_backend() == "nccl":
+        box = [capi.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return capi.Comm.rccl(ctx, box[0], world, rank)
+
+    def fn(buf, count, op, stream):
+        host = np.empty(count, dtype=np.float32 if op == capi.SUM_F32 else np.int32)
+        ctx.download(host.ctypes.data, buf, count * 4)            # blocking, ordered on the context's stream
+        t = torch.from_numpy(host)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN if op == capi.MIN_I32 else dist.ReduceOp.SUM)
+        ctx.upload(buf, host.ctypes.data, count * 4)
+        return 0
+
+    return capi.Comm.custom(world, rank, fn)
