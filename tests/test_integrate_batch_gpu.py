@@ -122,7 +122,10 @@ def test_batch_narrow_layouts_fall_back_frame_by_frame(gpu_ctx):
 
 
 def test_batch_512_equals_single_frame_kernel(gpu_ctx):
-    """BASELINE size: four orbit cameras 90 degrees apart (config C5's rig) into 512^3."""
+    """BASELINE size: four orbit cameras 90 degrees apart (config C5's rig) into 512^3.
+    This is also the GPU-side regression of the 16-byte store-data hazard: it was at this
+    size, in the batched kernel, that a v_cndmask scheduled into a store's data register reached memory instead of
+    the voxel; tools/check_store_hazard.py guards the same thing at build time."""
     n = 512
     dims, vs, tr = synth.volume_geometry(n)
     frames = frames_s2([0, 75, 150, 225])
