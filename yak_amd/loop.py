@@ -99,6 +99,9 @@ def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None, on_system=No
                                 k += 1
                         if on_system is not None:  # diagnostics: on_system(frame, level, A, b)
                             on_system(f, l, A, b)
+                        det = np.linalg.det(A)
+                        if not abs(det) >= 1e-15:  # projective_icp.cpp:215-222 (NaN fails too): estimateTransform gives up
+                            raise RuntimeError("ICP: singular normal equations at frame %d" % f)
                         x = np.linalg.solve(A, b)
                         Ri = rodrigues(x[:3])
                         R, t = Ri @ R, Ri @ t + x[3:]
@@ -116,12 +119,18 @@ def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None, on_system=No
         tv = -Rv @ pose_t
         ctx.integrate(desc, dists.data_ptr(), cols * 2, rows, cols, np.float32(Rv).reshape(-1), np.float32(tv), intr)
         e[3].record()
-        ctx.raycast_points(desc, np.float32(pose_R).reshape(-1), np.float32(pose_t), np.float32(Rv).reshape(-1), intr,
-                           prv_p[0].data_ptr(), cols * 16, prv_n[0].data_ptr(), cols * 16, rows, cols)
-        for l in range(1, LEVELS):
-            ctx.resize_points_normals(prv_p[l - 1].data_ptr(), (cols >> (l - 1)) * 16, prv_n[l - 1].data_ptr(),
-                                      (cols >> (l - 1)) * 16, rows >> (l - 1), cols >> (l - 1), prv_p[l].data_ptr(),
-                                      (cols >> l) * 16, prv_n[l].data_ptr(), (cols >> l) * 16)
+        if f == 0:
+            # kinfu.cpp:191-201: frame 0 integrates, its OWN point / normal maps become the first model maps
+            # (the pyramids are swapped), and there is no ray cast
+            cur_p, prv_p = prv_p, cur_p
+            cur_n, prv_n = prv_n, cur_n
+        else:
+            ctx.raycast_points(desc, np.float32(pose_R).reshape(-1), np.float32(pose_t), np.float32(Rv).reshape(-1), intr,
+                               prv_p[0].data_ptr(), cols * 16, prv_n[0].data_ptr(), cols * 16, rows, cols)
+            for l in range(1, LEVELS):
+                ctx.resize_points_normals(prv_p[l - 1].data_ptr(), (cols >> (l - 1)) * 16, prv_n[l - 1].data_ptr(),
+                                          (cols >> (l - 1)) * 16, rows >> (l - 1), cols >> (l - 1), prv_p[l].data_ptr(),
+                                          (cols >> l) * 16, prv_n[l].data_ptr(), (cols >> l) * 16)
         e[4].record()
         torch.cuda.synchronize()
         for name, a, b_ in (("preprocess", 0, 1), ("icp", 1, 2), ("integrate", 2, 3), ("raycast", 3, 4)):
