@@ -488,6 +488,9 @@ def main():
     ap.add_argument("--tile", type=int, default=0, help="wave footprint: log2 lanes along x, 3..6 (tuning)")
     ap.add_argument("--zu", type=int, default=0, help="layers per loop trip (tuning)")
     ap.add_argument("--stacked", action="store_true", help="waves of a workgroup stacked in y instead of side by side (tuning)")
+    ap.add_argument("--order", type=int, default=None, help="chunk_order option value (tuning)")
+    ap.add_argument("--chunk-min", type=int, default=None, help="chunk_min option value (tuning)")
+    ap.add_argument("--chunk-ramp", type=int, default=None, help="chunk_ramp option value (tuning)")
     ap.add_argument("--no-brick", action="store_true", help="switch the whole-brick test off (tuning)")
     ap.add_argument("--no-nt", action="store_true", help="plain instead of non-temporal volume accesses (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -566,6 +569,12 @@ def main():
         ctx.set_option("brick_test", 0)
     if args.stacked:
         ctx.set_option("tile_side", 0)
+    if args.order is not None:
+        ctx.set_option("chunk_order", args.order)
+    if args.chunk_min is not None:
+        ctx.set_option("chunk_min", args.chunk_min)
+    if args.chunk_ramp is not None:
+        ctx.set_option("chunk_ramp", args.chunk_ramp)
     if args.no_nt:
         ctx.set_option("nontemporal", 0)
     d_depth = torch.from_numpy(depth.view(np.int16)).cuda()

@@ -86,8 +86,10 @@ const char* yakhip_last_error(void);
  * whole workgroup bricks that cannot update, or update everywhere with tsdf 1, are settled before they are walked),
  * "checkpoint" (0/1: slabs with z0 >= 64 start from column positions computed in closed form instead of
  * replaying z0 additions per column), "tile" (0 or 3..6: wave footprint in the layer), "tile_side" (0/1: a workgroup's waves stacked in y / side by side in x), "mc_z_chunk"
- * (marching-cubes tile depth, 0 = auto), "kernel_timing" (0/1, see yakhip_ctx_kernel_time), "brick_stats" (0/1, see
- * yakhip_ctx_brick_stats), "composite_capacity" (list slots of yakhip_raycast_sharded's second step, 0 = auto),
+ * (marching-cubes tile depth, 0 = auto), "kernel_timing" (0/1, see yakhip_ctx_kernel_time), "chunk_order" (-1 auto, 0 z-chunks dispatched
+ * shallow to deep, 1 shallow / deep in turn, 3 deepest first), "chunk_min" / "chunk_ramp" (graded z-chunks of a volume walked from
+ * layer 0: a chunk that starts at layer zs is about zs / ramp layers long, at least chunk_min; 0 = auto, ramp -1 = all alike),
+ * "brick_stats" (0/1, see yakhip_ctx_brick_stats), "composite_capacity" (list slots of yakhip_raycast_sharded's second step, 0 = auto),
  * "zu" (ignored).
  * Unknown key or value -> YAKHIP_EINVAL. */
 int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value);

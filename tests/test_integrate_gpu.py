@@ -480,11 +480,18 @@ def test_integrate_brick_test_borders_near_plane_and_holes(gpu_ctx, seed):
             s = gpu_ctx.brick_stats()
             for k in s:
                 stats[k] = stats.get(k, 0) + s[k]
+        # the table of z-chunks (integrate.hip chunk_table): order, shortest chunk, growth
+        gpu_ctx.set_option("tile", 0)
+        for z_chunk, order, cmin, ramp in [(0, 0, 0, 0), (0, 1, 2, 2), (24, 3, 4, 8), (6, 3, 0, -1), (0, -1, 6, 3)]:
+            for key, v in [("z_chunk", z_chunk), ("chunk_order", order), ("chunk_min", cmin), ("chunk_ramp", ramp)]:
+                gpu_ctx.set_option(key, v)
+            assert_parity(run(), want)
         gpu_ctx.set_option("brick_test", 0)
         assert_parity(run(), want)
         assert sum(gpu_ctx.brick_stats().values()) > 0  # (all counted as mixed)
     finally:
-        for key, v in [("brick_test", 1), ("brick_stats", 0), ("z_chunk", 0), ("tile", 0), ("tile_side", 1)]:
+        for key, v in [("brick_test", 1), ("brick_stats", 0), ("z_chunk", 0), ("tile", 0), ("tile_side", 1),
+                       ("chunk_order", -1), ("chunk_min", 0), ("chunk_ramp", 0)]:
             gpu_ctx.set_option(key, v)
     assert stats["dead"] > 0 and stats["mixed"] > 0, stats  # the cases do reach the outcomes they are for
 

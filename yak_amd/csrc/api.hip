@@ -124,6 +124,9 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->zu = 0;
   ctx->group_test = 1;
   ctx->brick_test = 1;
+  ctx->chunk_order = -1;
+  ctx->chunk_min = 0;
+  ctx->chunk_ramp = 0;
   ctx->checkpoint = 1;
   ctx->tile_shift = 0;
   ctx->tile_side = 1;
@@ -267,6 +270,21 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
   if (strcmp(key, "brick_test") == 0)
   {
     ctx->brick_test = value != 0;
+    return 0;
+  }
+  if (strcmp(key, "chunk_order") == 0)
+  {
+    ctx->chunk_order = (int)value;
+    return 0;
+  }
+  if (strcmp(key, "chunk_min") == 0)
+  {
+    ctx->chunk_min = (int)value;
+    return 0;
+  }
+  if (strcmp(key, "chunk_ramp") == 0)
+  {
+    ctx->chunk_ramp = (int)value;
     return 0;
   }
   if (strcmp(key, "brick_stats") == 0)

@@ -625,9 +625,6 @@ __device__ __forceinline__ void update(const IntegrateParams& p, const Pos<VX>& 
   buf = buf_load<VX, NT>(rs, lanes(buf_valid) ? voff : kNoAccess, ahead_ok ? soff + 2u * layer_bytes : 0u);
 }
 
-// blockIdx.y -> z-chunk: in order, or 0, n - 1, 1, n - 2, ... (see integrate_kernel)
-__device__ __forceinline__ int chunk_of_block(int j, int n, int alt) { return alt && (j & 1) ? n - 1 - (j >> 1) : (alt ? j >> 1 : j); }
-
 // Which voxels of a layer a lane owns.  tile_shift == 6: lanes in layer order, a wave = 64 * VX voxels of
 // one x-row.  Smaller shifts fold the wave into a compact tile -- 2^shift lanes (2^shift * VX voxels,
 // still >= 128 contiguous bytes) along x times 64 >> shift rows, the four waves of a workgroup stacked
@@ -851,35 +848,31 @@ __device__ __forceinline__ void walk_front(const IntegrateParams& p, rsrc_t rs, 
 // sets (A, B): while layer z is being settled and written, layer z+1 is already tested/projected
 // (its threshold gathers in flight), and the voxels of layers z+1 / z+2 are being fetched.
 template <int VX, bool NT>
-__global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams p)
+__global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams p, const ChunkTable chunks)
 {
   typedef typename Vec<VX>::type vec_t;
   extern __shared__ __attribute__((aligned(16))) float coarse_lds[];
 
-  // Chunks are handed out shallow and deep in turn (0, n-1, 1, n-2, ...).  In plain ascending order the deep
-  // chunks -- the longest replays, and on a scene seen from the front the ones that hold the surface -- all
-  // come last and make the tail; deepest first, every wave of a SIMD replays at once with no traffic to
-  // hide behind (wall scene 0.215-0.235 ms).  Measured at 512^3, kernel / whole step: S0 0.1891 / 0.1942 ->
-  // 0.1884 / 0.1917 ms, S1 0.252 -> 0.237, S2 0.2725 -> 0.265.  Only for a volume that replays from layer 0:
-  // a slab that starts from a checkpoint has short replays everywhere and streams better in order (rank 7 of 8
-  // at 1024^3: 0.201 ms in order, 0.216 alternating), and so do the 4 MiB layers of wide slabs (rank 0: 0.196 / 0.206).
-  const int zs = p.z0 + chunk_of_block((int)blockIdx.y, (int)gridDim.y, p.chunk_alt) * p.z_chunk;
-  const int ze = min(zs + p.z_chunk, p.z1);
+  // The chunk this workgroup walks comes from the launcher's table (chunk_table below): layers [zs, ze), in the
+  // order the launcher wants them dispatched.
+  const int zs = p.z0 + __builtin_amdgcn_readfirstlane((int)chunks.first[blockIdx.y]);
+  const int ze = zs + __builtin_amdgcn_readfirstlane((int)chunks.layers[blockIdx.y]);
 
-  // each wave's brick first: most of a real frame's bricks end here.  The coarse threshold image (a few KiB,
-  // read once per workgroup into LDS) is only needed by mixed bricks; the waves agree on it through LDS.
-  __shared__ int wave_class[4];
-  const int brick = p.brick_enable ? classify_brick<VX>(p, zs, ze) : kBrickMixed;
-  bool fill = VX == 4 && p.grp_enable;
+  // brick test: wave-uniform class of this wave's brick
+  const int cls = p.brick_enable ? classify_brick<VX>(p, zs, ze) : kBrickMixed;
   if (p.brick_stats && (threadIdx.x & 63u) == 0)  // measurement aid, off by default
-    atomicAdd(&p.brick_stats[brick], 1u);
+    atomicAdd(&p.brick_stats[cls], 1u);
+
+  // The coarse threshold image (a few KiB, read once per workgroup into LDS) is only needed by mixed bricks; the
+  // waves of the workgroup agree on it through LDS.
+  __shared__ int wave_mixed[4];
+  bool fill = VX == 4 && p.grp_enable;
   if (p.brick_enable)
   {
     if ((threadIdx.x & 63u) == 0)
-      wave_class[threadIdx.x >> 6] = brick;
+      wave_mixed[threadIdx.x >> 6] = cls == kBrickMixed;
     __syncthreads();
-    fill = fill && (wave_class[0] == kBrickMixed || wave_class[1] == kBrickMixed || wave_class[2] == kBrickMixed ||
-                    wave_class[3] == kBrickMixed);
+    fill = fill && (wave_mixed[0] || wave_mixed[1] || wave_mixed[2] || wave_mixed[3]);
   }
   if (fill)
   {
@@ -888,7 +881,7 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
       coarse_lds[i] = p.coarse[i];
     __syncthreads();
   }
-  if (brick == kBrickDead)
+  if (cls == kBrickDead)
     return;
 
   uint32_t elem;  // x + y*X of the lane's first voxel; X % VX == 0 so no row straddle
@@ -897,7 +890,7 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
     return;
   const mask_t active = ballot(true);
 
-  if (brick == kBrickFront)
+  if (cls == kBrickFront)
   {
     const uint32_t lb = p.plane * 4u;
     const rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(p.vol + (size_t)(zs - p.z0) * p.plane, 0,
@@ -905,6 +898,7 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
     walk_front<VX, NT>(p, rsf, elem * 4u, lb, ze - zs, active, ((uint32_t)p.max_weight << 16) | 0xffffu);
     return;
   }
+  const int ws = zs, we = ze;  // the layers walked voxel by voxel
 
   // :69
   const float zsx = p.R[2] * p.vsz, zsy = p.R[5] * p.vsz, zsz = p.R[8] * p.vsz;
@@ -926,9 +920,9 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
       A.z[k][h] = dot3(p.R[6], p.R[7], p.R[8], vxx, vxy, 0.f) + p.t[2];
     }
 
-  // Replay the additions the reference performed on layers [0, zs) (tsdf_volume.cu:76) -- from layer 0, or
+  // Replay the additions the reference performed on layers [0, zs) (tsdf_volume.cu:76), ws of them here -- from layer 0, or
   // for a slab deep inside a tall volume from the column positions at z0 that checkpoint_kernel left.
-  int replay = zs;
+  int replay = ws;
   if (p.ckpt)
   {
 #pragma unroll
@@ -942,7 +936,7 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
         A.y[k][h] = p.ckpt[p.plane + col];
         A.z[k][h] = p.ckpt[2u * p.plane + col];
       }
-    replay = zs - p.z0;
+    replay = ws - p.z0;
   }
   for (int i = 0; i < replay; ++i)
     advance<VX>(A, A, sx, sy, sz);
@@ -950,10 +944,10 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
   const f32x2 fx2 = { p.fx, p.fx }, fy2 = { p.fy, p.fy }, cx2 = { p.cx, p.cx }, cy2 = { p.cy, p.cy };
   const uint32_t max_w_hi = ((uint32_t)p.max_weight << 16) | 0xffffu;
 
-  // descriptor over this chunk's layers [zs, ze); the launcher keeps it below 2 GiB
+  // descriptor over the walked layers [ws, we); the launcher keeps a chunk below 2 GiB
   const uint32_t layer_bytes = p.plane * 4u;
-  const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.vol + (size_t)(zs - p.z0) * p.plane, 0,
-                                                      (uint32_t)(ze - zs) * layer_bytes, 0x00020000);
+  const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.vol + (size_t)(ws - p.z0) * p.plane, 0,
+                                                      (uint32_t)(we - ws) * layer_bytes, 0x00020000);
   const uint32_t voff = elem * 4u;
 
   // Prologue, shaped like one steady-state half trip so that the compiler's s_waitcnt counting sees
@@ -961,7 +955,7 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
   // The first two layers are fetched for every lane (nothing is known about them yet); the store is
   // a no-op (every lane out of range).
   Probe<VX> PA, PB;
-  mask_t validA = ~0ull, validB = zs + 1 < ze ? ~0ull : 0ull;
+  mask_t validA = ~0ull, validB = ws + 1 < we ? ~0ull : 0ull;
   vec_t bufA = buf_load<VX, NT>(rs, voff, 0u);
   __builtin_amdgcn_sched_barrier(0);
   stage1<VX>(p, A, PA, coarse_lds, active, fx2, fy2, cx2, cy2);
@@ -970,22 +964,22 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
   vec_t bufB = buf_load<VX, NT>(rs, validB ? voff : kNoAccess, validB ? layer_bytes : 0u);
   __builtin_amdgcn_sched_barrier(0);
   uint32_t soff = 0;
-  for (int z = zs; z < ze; z += 2, soff += 2u * layer_bytes)
+  for (int z = ws; z < we; z += 2, soff += 2u * layer_bytes)
   {
     // layer z lives in set A, layer z+1 in set B.  Stage 1 runs one layer ahead and is not guarded at
-    // the chunk end: a projection past ze reads valid threshold texels and is discarded.
+    // the walk's end: a projection past we reads valid threshold texels and is discarded.
     advance<VX>(A, B, sx, sy, sz);
     stage1<VX>(p, B, PB, coarse_lds, active, fx2, fy2, cx2, cy2);
-    update<VX, NT>(p, A, PA, bufA, validA, rs, voff, soff, layer_bytes, true, z + 2 < ze, max_w_hi);
+    update<VX, NT>(p, A, PA, bufA, validA, rs, voff, soff, layer_bytes, true, z + 2 < we, max_w_hi);
     advance<VX>(B, A, sx, sy, sz);
     stage1<VX>(p, A, PA, coarse_lds, active, fx2, fy2, cx2, cy2);
-    update<VX, NT>(p, B, PB, bufB, validB, rs, voff, soff + layer_bytes, layer_bytes, z + 1 < ze, z + 3 < ze,
+    update<VX, NT>(p, B, PB, bufB, validB, rs, voff, soff + layer_bytes, layer_bytes, z + 1 < we, z + 3 < we,
                    max_w_hi);
   }
 }
 
 template <int VX>
-static int launch_variant(yakhip_ctx* ctx, const IntegrateParams& p, dim3 grid, bool use_static)
+static int launch_variant(yakhip_ctx* ctx, const IntegrateParams& p, const ChunkTable& chunks, dim3 grid, bool use_static)
 {
   const size_t lds = VX == 4 && p.grp_enable ? (size_t)p.cw * p.ch * sizeof(float) : 0;
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
@@ -993,9 +987,9 @@ static int launch_variant(yakhip_ctx* ctx, const IntegrateParams& p, dim3 grid, 
   if (rc != 0)                                       // (it may create events: not on the allocation-free path)
     return rc;
   if (ctx->nontemporal)
-    hipLaunchKernelGGL((integrate_kernel<VX, true>), grid, dim3(256), lds, ctx->stream, p);
+    hipLaunchKernelGGL((integrate_kernel<VX, true>), grid, dim3(256), lds, ctx->stream, p, chunks);
   else
-    hipLaunchKernelGGL((integrate_kernel<VX, false>), grid, dim3(256), lds, ctx->stream, p);
+    hipLaunchKernelGGL((integrate_kernel<VX, false>), grid, dim3(256), lds, ctx->stream, p, chunks);
   if ((rc = timing_end(ctx, ev)) != 0)
     return rc;
   return check(hipGetLastError(), "integrate_kernel launch");
@@ -1154,6 +1148,13 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
   return 0;
 }
 
+// A volume that replays from layer 0 and has layers below 4 MiB gets chunks of graded length, deepest first
+// (chunk_table below).
+static bool graded_chunks(const yakhip_ctx* ctx, const IntegrateParams& p)
+{
+  return ctx->chunk_ramp >= 0 && !p.ckpt && p.z0 == 0 && (uint64_t)p.plane * 4u < (4ull << 20);
+}
+
 // z_chunk and grid for a plane of `blocks_x` workgroups.  Short chunks balance the load: the cost of a
 // chunk depends on how much surface it holds (per-voxel path, band arithmetic), and with a few long
 // chunks per column the last workgroups of a surface-rich frame run alone (measured at 512^3: 171-layer
@@ -1164,17 +1165,19 @@ static int choose_chunk(const yakhip_ctx* ctx, const IntegrateParams& p, uint32_
                         int min_chunk, int* chunk_out, uint32_t* nchunks_out)
 {
   const int layers = p.z1 - p.z0;
+  const bool graded = graded_chunks(ctx, p);
   int chunk = ctx->z_chunk;
   if (chunk <= 0)
   {
-    chunk = (layers + 15) / 16;
+    // (a volume walked from layer 0 in a graded table, see chunk_table: 24-layer chunks at 512 layers, measured)
+    chunk = graded ? (layers / 21) & ~1 : (layers + 15) / 16;
     if (chunk < min_chunk)
       chunk = min_chunk;
     // A chunk that starts at layer zs replays zs steps before its own `chunk` layers.  While the average
     // replay stays below about 8 steps per layer of real work it hides behind the memory traffic (a whole
     // 512-layer volume in 32-layer chunks: 256 / 32); a slab deep inside a tall volume needs longer chunks
     // for that (measured, rank 7 of 8 at 1024^3, layers [896, 1024): 0.264 ms with 32-layer chunks).
-    const int for_replay = ((p.ckpt ? 0 : p.z0) + layers / 2) / 8;  // (with a checkpoint the replay starts at z0)
+    const int for_replay = ((p.ckpt ? 0 : p.z0) + layers / 2) / (graded ? 12 : 8);  // (with a checkpoint the replay starts at z0)
     if (chunk < for_replay)
     {
       const int n = layers / for_replay > 1 ? layers / for_replay : 1;
@@ -1198,6 +1201,70 @@ static int choose_chunk(const yakhip_ctx* ctx, const IntegrateParams& p, uint32_
   *chunk_out = chunk;
   *nchunks_out = nchunks;
   return 0;
+}
+
+// The chunks of a launch, in dispatch order (grid.y index -> layers).  Returns their number (0: they do not fit).
+//
+// Two things decide how long a frame's last workgroups run on alone, and with it 5-10 % of the kernel time:
+//   order   a workgroup costs its replay (zs steps) plus its walk, so the deepest chunks are the longest jobs:
+//           they go first (longest job first), the shallow ones fill the gaps at the end;
+//   size    where the replay is short a chunk can be short too without the replay taking over: a chunk that
+//           starts at layer zs is about zs / ramp layers long, between min_layers and `chunk`.  The short,
+//           cheap chunks are the ones dispatched last, so the tail is made of small jobs.
+// Measured at 512^3 (kernel time, 32-layer chunks shallow / deep in turn -> this table): see DESIGN.md 3.1.
+// Only for a volume that replays from layer 0 and has layers below 4 MiB: a slab that starts from a checkpoint
+// has short replays everywhere and streams better in order (rank 7 of 8 at 1024^3: 0.201 ms in order, 0.216
+// alternating), and so do the 4 MiB layers of wide slabs (rank 0: 0.196 / 0.206).
+static uint32_t chunk_table(const yakhip_ctx* ctx, const IntegrateParams& p, int chunk, int min_layers, ChunkTable* out)
+{
+  const int layers = p.z1 - p.z0;
+  const bool from_zero = !p.ckpt && p.z0 == 0 && (uint64_t)p.plane * 4u < (4ull << 20);
+  const int order = ctx->chunk_order >= 0 ? ctx->chunk_order : (from_zero ? 3 : 0);
+  const int ramp = ctx->chunk_ramp > 0 ? ctx->chunk_ramp : 6;
+  if (ctx->chunk_min > 0)
+    min_layers = ctx->chunk_min;
+  bool graded = graded_chunks(ctx, p) && min_layers < chunk;
+  uint32_t first[kMaxChunks];
+  uint16_t count[kMaxChunks];
+  uint32_t n;
+  for (;;)
+  {
+    n = 0;
+    int z = 0;
+    while (z < layers && n < (uint32_t)kMaxChunks)
+    {
+      int len = chunk;
+      if (graded)
+      {
+        len = (z / ramp + 1) & ~1;  // even: the walk takes layers in pairs
+        len = len < min_layers ? min_layers : (len > chunk ? chunk : len);
+      }
+      if (len > layers - z)
+        len = layers - z;
+      first[n] = (uint32_t)z;
+      count[n] = (uint16_t)len;
+      ++n;
+      z += len;
+    }
+    if (z >= layers)
+      break;
+    // too many chunks for the table: plain chunks, as long as it takes (choose_chunk keeps them below 65536 layers)
+    graded = false;
+    chunk = (layers + kMaxChunks - 1) / kMaxChunks > chunk ? (layers + kMaxChunks - 1) / kMaxChunks : chunk + 1;
+  }
+  if ((uint64_t)chunk * p.plane * 4u > 0x7fffffffull)
+    return 0;  // (one buffer descriptor spans a chunk, see choose_chunk; no volume that fits the card gets here)
+  for (uint32_t j = 0; j < n; ++j)
+  {
+    uint32_t i = j;  // 0: ascending
+    if (order == 1)
+      i = (j & 1u) ? n - 1u - (j >> 1) : j >> 1;  // shallow and deep in turn
+    else if (order == 3)
+      i = n - 1u - j;  // deepest first
+    out->first[j] = first[i];
+    out->layers[j] = count[i];
+  }
+  return n;
 }
 
 // Largest compact tile (see lane_voxels) that divides the layer exactly; 6 = plain layer order.
@@ -1249,21 +1316,22 @@ int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in, bool use_stat
   // four single-frame calls on the orbit rig over a 2048 x 2048 x 256 slab take 7.9 ms in 16-layer walks, 6.7 in
   // 32-layer and 6.1 in 64-layer ones (tools/bench_c5.py --z-chunk), the bare sweep 209 / 231 us per 2^27 voxels.
   const uint64_t layer_bytes = (uint64_t)p.plane * 4u;
-  const int min_chunk = layer_bytes >= (4ull << 20) && layer_bytes < (16ull << 20) ? 16 : 32;
+  const int min_chunk = layer_bytes >= (4ull << 20) && layer_bytes < (16ull << 20) ? 16 : (graded_chunks(ctx, p) ? 24 : 32);
   if ((rc = choose_chunk(ctx, p, blocks_x, 768u, min_chunk, &chunk, &nchunks)) != 0)
     return rc;
   p.z_chunk = chunk;
-  p.chunk_alt = !p.ckpt && p.z0 == 0 && (uint64_t)p.plane * 4u < (4ull << 20);
-
-  const dim3 grid(blocks_x, nchunks);
+  ChunkTable chunks;
+  const dim3 grid(blocks_x, chunk_table(ctx, p, chunk, 8, &chunks));
+  if (grid.y == 0)
+    return fail(YAKHIP_ERANGE, "integrate: the volume needs more than %d z-chunks of at most 2 GiB", kMaxChunks);
   switch (vx)
   {
     case 4:
-      return launch_variant<4>(ctx, p, grid, use_static);
+      return launch_variant<4>(ctx, p, chunks, grid, use_static);
     case 2:
-      return launch_variant<2>(ctx, p, grid, use_static);
+      return launch_variant<2>(ctx, p, chunks, grid, use_static);
     default:
-      return launch_variant<1>(ctx, p, grid, use_static);
+      return launch_variant<1>(ctx, p, chunks, grid, use_static);
   }
 }
 
@@ -1285,7 +1353,7 @@ struct BatchParams
 };
 
 template <int K, bool NT>
-__global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchParams bp)
+__global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchParams bp, const ChunkTable chunks)
 {
   constexpr int VX = 4;
   typedef Vec<VX>::type vec_t;
@@ -1293,8 +1361,8 @@ __global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchPara
   const IntegrateParams& p = bp.f[0];
 
   const int cells = p.cw * p.ch;  // the same for every frame: same image size, same cell size
-  const int zs = p.z0 + chunk_of_block((int)blockIdx.y, (int)gridDim.y, p.chunk_alt) * p.z_chunk;  // as the single-frame kernel
-  const int ze = min(zs + p.z_chunk, p.z1);
+  const int zs = p.z0 + __builtin_amdgcn_readfirstlane((int)chunks.first[blockIdx.y]);  // as the single-frame kernel
+  const int ze = zs + __builtin_amdgcn_readfirstlane((int)chunks.layers[blockIdx.y]);
 
   // the wave's brick against every frame (classify_brick): a frame that cannot touch it is skipped for the
   // whole chunk, one that updates all of it with tsdf 1 needs no projection; only mixed frames are walked
@@ -1441,16 +1509,16 @@ __global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchPara
 }
 
 template <int K>
-static int launch_batch_variant(yakhip_ctx* ctx, const BatchParams& bp, dim3 grid, size_t lds)
+static int launch_batch_variant(yakhip_ctx* ctx, const BatchParams& bp, const ChunkTable& chunks, dim3 grid, size_t lds)
 {
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   int rc = timing_begin(ctx, &ev);
   if (rc != 0)
     return rc;
   if (ctx->nontemporal)
-    hipLaunchKernelGGL((integrate_batch_kernel<K, true>), grid, dim3(256), lds, ctx->stream, bp);
+    hipLaunchKernelGGL((integrate_batch_kernel<K, true>), grid, dim3(256), lds, ctx->stream, bp, chunks);
   else
-    hipLaunchKernelGGL((integrate_batch_kernel<K, false>), grid, dim3(256), lds, ctx->stream, bp);
+    hipLaunchKernelGGL((integrate_batch_kernel<K, false>), grid, dim3(256), lds, ctx->stream, bp, chunks);
   if ((rc = timing_end(ctx, ev)) != 0)
     return rc;
   return check(hipGetLastError(), "integrate_batch_kernel launch");
@@ -1513,20 +1581,22 @@ int launch_integrate_batch(yakhip_ctx* ctx, const IntegrateParams* frames, int n
       bp.f[i].z_chunk = chunk;
       bp.f[i].tile_shift = tile;
       bp.f[i].tile_side = ctx->tile_side;
-      bp.f[i].chunk_alt = !bp.f[0].ckpt && bp.f[0].z0 == 0 && (uint64_t)bp.f[0].plane * 4u < (4ull << 20);
     }
-    const dim3 grid(blocks_x, nchunks);
+    ChunkTable chunks;
+    const dim3 grid(blocks_x, chunk_table(ctx, bp.f[0], chunk, 16, &chunks));
+    if (grid.y == 0)
+      return fail(YAKHIP_ERANGE, "integrate: the volume needs more than %d z-chunks of at most 2 GiB", kMaxChunks);
     const size_t lds = grp ? (size_t)k * bp.f[0].cw * bp.f[0].ch * sizeof(float) : 0;
     switch (k)
     {
       case 2:
-        rc = launch_batch_variant<2>(ctx, bp, grid, lds);
+        rc = launch_batch_variant<2>(ctx, bp, chunks, grid, lds);
         break;
       case 3:
-        rc = launch_batch_variant<3>(ctx, bp, grid, lds);
+        rc = launch_batch_variant<3>(ctx, bp, chunks, grid, lds);
         break;
       default:
-        rc = launch_batch_variant<4>(ctx, bp, grid, lds);
+        rc = launch_batch_variant<4>(ctx, bp, chunks, grid, lds);
         break;
     }
     if (rc != 0)

@@ -19,6 +19,9 @@ struct yakhip_ctx
   int force_vx;        // 0 = widest the layout allows; 1/2/4 caps the voxels per lane
   int zu;              // (unused; kept for option compatibility)
   int group_test;      // coarse group test on (default) / off
+  int chunk_order;     // -1 automatic; 0 ascending, 1 shallow / deep in turn, 3 deepest first (tuning)
+  int chunk_min;       // 0 automatic; shortest chunk of a graded table, layers (tuning)
+  int chunk_ramp;      // 0 automatic (6); a chunk starting at layer zs is about zs / ramp layers long; -1: all chunks alike (tuning)
   int brick_test;      // classify whole bricks (dead / front / mixed) before walking them (default) / off
   int checkpoint;      // deep slabs start from closed-form column positions (default) / replay from layer 0
   int tile_shift;      // 0 = default wave footprint, else 3..6 (tuning)
@@ -89,8 +92,7 @@ struct IntegrateParams
   int rows, cols;
   int X, Y;              // in-plane extent
   int z0, z1;            // owned layers
-  int z_chunk;           // layers walked by one workgroup (grid.y index)
-  int chunk_alt;         // 1: chunks are handed out shallow and deep in turn (integrate.hip chunk_of_block)
+  int z_chunk;           // longest chunk of the launch, layers (the chunks themselves: ChunkTable)
   int tile_shift;        // log2 of the lanes a wave lays along x (6 = layer order); integrate.hip lane_voxels()
   int tile_side;         // waves of a workgroup side by side along x (1) or stacked in y (0)
   uint32_t plane;        // X * Y
@@ -101,6 +103,15 @@ struct IntegrateParams
   float R[9];
   float t[3];
   float fx, fy, cx, cy;
+};
+
+// The z-chunks of an integrate launch in dispatch order, passed by value beside IntegrateParams: workgroups with
+// blockIdx.y == j walk layers [z0 + first[j], z0 + first[j] + layers[j]).  integrate.hip, chunk_table().
+constexpr int kMaxChunks = 128;
+struct ChunkTable
+{
+  uint32_t first[kMaxChunks];
+  uint16_t layers[kMaxChunks];
 };
 
 // Ray casting (raycast.hip).  Everything wave-uniform travels in the kernarg segment.
