@@ -91,7 +91,10 @@ def next_rows(ctx, torch, capi, synth, with_cpu):
     rows, cols, intr = synth.ROWS, synth.COLS, synth.INTR
     dims, vs, tr = synth.volume_geometry(n)
     vol = torch.zeros(n ** 3, dtype=torch.int32, device="cuda")
-    desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT)
+    plain = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT)
+    # with its surface map (one bit per 16^3 brick, kept by integrate, consulted by the ray cast: include/yakhip.h)
+    smap = torch.zeros(capi.surface_map_bytes(plain) // 4, dtype=torch.int32, device="cuda")
+    desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT, surface_map=smap.data_ptr())
     frames, keep = [], []
     for f in range(0, 300, 38):
         depth, R, t = synth.scene_s2(f)
@@ -117,16 +120,45 @@ def next_rows(ctx, torch, capi, synth, with_cpu):
     ctx.integrate_batch(desc, frames[4:])
     out["integrate_batch_k4_s2_ms_per_frame"] = round(timed(lambda: ctx.integrate_batch(desc, frames[:4]), 5) / 4, 4)
 
-    # raycast from an orbit pose (cam2vol = inverse of vol2cam)
-    _, R_v2c, t_v2c = synth.scene_s2(19)
-    Rc = np.ascontiguousarray(R_v2c.T)
-    tc = (-(R_v2c.astype(np.float64).T @ t_v2c.astype(np.float64))).astype(np.float32)
+    # raycast from orbit poses (cam2vol = inverse of vol2cam): along the volume's z axis (views 0, 150) and
+    # oblique (37, 100, 222), with the surface map and without it
     pts = torch.empty((rows, cols, 4), dtype=torch.float32, device="cuda")
     nrm = torch.empty_like(pts)
-    ms = timed(lambda: ctx.raycast_points(desc, Rc.reshape(-1), tc, R_v2c.reshape(-1), intr, pts.data_ptr(), cols * 16,
-                                          nrm.data_ptr(), cols * 16, rows, cols), 20)
-    hits = int((~torch.isnan(pts[..., 0])).sum().item())
-    out["raycast"] = {"ms": round(ms, 4), "rays": rows * cols, "hits": hits, "bound": "gather latency"}
+    per_view, per_view_plain, samples, hits = {}, {}, 0, 0
+    step = tr * 0.75
+    for view in (0, 37, 100, 150, 222):
+        _, R_v2c, t_v2c = synth.scene_s2(view)
+        Rc = np.ascontiguousarray(R_v2c.T)
+        tc = (-(R_v2c.astype(np.float64).T @ t_v2c.astype(np.float64))).astype(np.float32)
+        for d, sink in ((plain, per_view_plain), (desc, per_view)):
+            sink[str(view)] = round(timed(lambda: ctx.raycast_points(d, Rc.reshape(-1), tc, R_v2c.reshape(-1), intr, pts.data_ptr(),
+                                                                     cols * 16, nrm.data_ptr(), cols * 16, rows, cols), 20), 4)
+        # samples the march takes (tsdf_volume.cu:149-165, 306-324): from the volume's near face to the hit, or
+        # to its far face; float64 on the host, a count for the byte figure below, not a parity statement
+        v = pts.cpu().numpy().astype(np.float64)
+        hit = ~np.isnan(v[..., 0])
+        u, w = np.meshgrid((np.arange(cols) - intr[2]) / intr[0], (np.arange(rows) - intr[3]) / intr[1])
+        dirs = np.stack([u, w, np.ones_like(u)], -1) @ Rc.astype(np.float64).T
+        dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            box = np.array([vs[i] * dims[i] - vs[i] for i in range(3)])
+            ta, tb = (0.0 - tc) / dirs, (box - tc) / dirs
+        tmin = np.maximum(np.minimum(ta, tb).max(-1), 0.0)
+        tmax = np.maximum(ta, tb).min(-1)
+        t_end = np.where(hit, np.linalg.norm(v[..., :3], axis=-1), tmax)
+        samples += int(np.clip((t_end - tmin) / step, 0, None)[tmin < tmax].sum())
+        hits += int(hit.sum())
+    ms = float(np.mean(list(per_view.values())))
+    # per ray cast: one half per sample, 2 + 6 trilinear taps of 8 halves per hit, 32 B of maps per pixel
+    rc_bytes = (2 * samples + 2 * 64 * hits) // 5 + 32 * rows * cols
+    out["raycast"] = {"ms": round(ms, 4), "ms_per_view": per_view, "ms_per_view_without_surface_map": per_view_plain,
+                      "rays": rows * cols, "hits_mean": hits // 5, "samples_mean": samples // 5,
+                      "roofline": {"bound": "hbm", "achieved": round(rc_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                                   "unit": "GB/s", "frac": round(rc_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                   "algorithmic_bytes": rc_bytes, "traffic": None},
+                      "note": "not bound by HBM: the march is one dependent chain of samples per ray (position, nearest voxel, "
+                              "sign test); with the surface map the samples of free space are settled from LDS and the kernel "
+                              "is bound by VALU issue, without it by gathers of 2 B per 64 B sector"}
 
     # one ICP linearisation at full resolution: the ray-cast maps against themselves
     def icp():

@@ -60,7 +60,25 @@ typedef struct yakhip_volume
   float voxel_size[3];  /* metres per voxel (TsdfVolume::getVoxelSize, yak/src/kfusion/tsdf_volume.cpp:45-48) */
   float trunc_dist;     /* metres (tsdf_volume.cpp:62-67) */
   int max_weight;       /* 1..32767 */
+  void* surface_map;    /* NULL, or device memory of yakhip_surface_map_bytes() bytes (4-byte aligned): see below */
 } yakhip_volume;
+
+/* The surface map of a slab (no counterpart in the reference; optional): one bit per brick of
+ * YAKHIP_SURFACE_BRICK^3 voxels of the slab's layers [z0, z1) -- bit (bx + BX * (by + BY * bz)) of an array of
+ * 32-bit words, BX = ceil(X / 16), BY = ceil(Y / 16), bz counted from layer z0 -- set when the brick MAY hold a voxel
+ * with a negative tsdf.  The ray cast can only stop between two samples of which one is negative
+ * (yak/src/cuda/tsdf_volume.cu:326-331), so it does not fetch the samples that fall into bricks whose bit is
+ * clear; the images are the same bit for bit, with or without a map.
+ *   yakhip_integrate / _static / _batch   set the bits of the bricks in which a negative measurement was folded
+ *                                         into a voxel (nothing else can make a voxel negative);
+ *   yakhip_clear_volume                   clears the map with the voxels;
+ *   yakhip_raycast_* (and _slab/_sharded) consult it;
+ *   yakhip_surface_map_rebuild            recomputes it from the voxels.
+ * The map belongs to one (data, z0, z1): pass the same three with it every time.  Whoever writes voxels by other
+ * means (an upload, a copy, a kernel of his own) calls yakhip_surface_map_rebuild before the next ray cast, or
+ * passes NULL.  A stale SET bit is harmless. */
+#define YAKHIP_SURFACE_BRICK 16
+int yakhip_surface_map_bytes(const yakhip_volume* vol, size_t* bytes);
 
 /* ---- context ------------------------------------------------------------------------------ */
 
@@ -89,6 +107,7 @@ const char* yakhip_last_error(void);
  * (marching-cubes tile depth, 0 = auto), "kernel_timing" (0/1, see yakhip_ctx_kernel_time), "chunk_order" (-1 auto, 0 z-chunks dispatched
  * shallow to deep, 1 shallow / deep in turn, 3 deepest first), "chunk_min" / "chunk_ramp" (graded z-chunks of a volume walked from
  * layer 0: a chunk that starts at layer zs is about zs / ramp layers long, at least chunk_min; 0 = auto, ramp -1 = all alike),
+ * "surface_skip" (0/1: the ray cast consults / ignores yakhip_volume.surface_map),
  * "brick_stats" (0/1, see yakhip_ctx_brick_stats), "composite_capacity" (list slots of yakhip_raycast_sharded's second step, 0 = auto),
  * "zu" (ignored).
  * Unknown key or value -> YAKHIP_EINVAL. */
@@ -140,6 +159,10 @@ int yakhip_copy_2d(yakhip_ctx* ctx, void* dst_dev, size_t dst_pitch, const void*
 /* Replaces kfusion::device::clear_volume (internal.hpp:125; yak/src/cuda/tsdf_volume.cu:14-40):
  * every voxel of the slab <- pack_tsdf(0, 0) = 0x00000000. */
 int yakhip_clear_volume(yakhip_ctx* ctx, const yakhip_volume* vol);
+
+/* vol->surface_map <- the bricks of vol's layers that hold a voxel with a negative tsdf (one sweep over the
+ * voxels).  Not blocking.  No counterpart in the reference. */
+int yakhip_surface_map_rebuild(yakhip_ctx* ctx, const yakhip_volume* vol);
 
 /* Replaces kfusion::device::compute_dists (internal.hpp:150; yak/src/cuda/imgproc.cu:259-283):
  * dists(y,x) = half_rn(depth_mm(y,x) * sqrt(xl^2 + yl^2 + 1) * 0.001), xl = (x - cx)/fx.

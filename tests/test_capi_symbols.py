@@ -36,11 +36,11 @@ def test_python_binding_covers_every_declared_symbol():
 
 
 def test_volume_struct_layout_matches_header():
-    # struct yakhip_volume: void*, int[3], int, int, float[3], float, int
-    assert ctypes.sizeof(capi.VolumeDesc) == 8 + 12 + 8 + 12 + 4 + 4
+    # struct yakhip_volume: void*, int[3], int, int, float[3], float, int, void*
+    assert ctypes.sizeof(capi.VolumeDesc) == 8 + 12 + 8 + 12 + 4 + 4 + 8
     assert capi.VolumeDesc.data.offset == 0 and capi.VolumeDesc.dims.offset == 8
     assert capi.VolumeDesc.z0.offset == 20 and capi.VolumeDesc.voxel_size.offset == 28
-    assert capi.VolumeDesc.max_weight.offset == 44
+    assert capi.VolumeDesc.max_weight.offset == 44 and capi.VolumeDesc.surface_map.offset == 48
 
 
 def test_no_gpu_is_an_error_not_a_fallback():

@@ -23,7 +23,9 @@ def main():
     n = args.n
     dims, vs, tr = synth.volume_geometry(n)
     vol = torch.zeros(n ** 3, dtype=torch.int32, device="cuda")
-    desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT)
+    plain = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT)
+    smap = torch.zeros(capi.surface_map_bytes(plain) // 4, dtype=torch.int32, device="cuda")
+    desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT, surface_map=smap.data_ptr())
     d_dists = torch.empty((synth.ROWS, synth.COLS), dtype=torch.int16, device="cuda")
     for f in range(0, 300, 15):
         depth, R, t = synth.scene_s2(f)
@@ -32,24 +34,38 @@ def main():
                           synth.INTR)
         ctx.integrate(desc, d_dists.data_ptr(), synth.COLS * 2, synth.ROWS, synth.COLS, R.reshape(-1), t, synth.INTR)
     torch.cuda.synchronize()
+    marked = int(sum(bin(int(w) & 0xffffffff).count("1") for w in smap.cpu().numpy()))
+    kept = smap.clone()
+    ctx.surface_map_rebuild(desc)
+    torch.cuda.synchronize()
+    exact = int(sum(bin(int(w) & 0xffffffff).count("1") for w in smap.cpu().numpy()))
+    missing = int((smap & ~kept).ne(0).sum().item())
+    print("surface map: %d bricks marked by integrate, %d hold a negative voxel, %d of those unmarked (must be 0), %d bricks"
+          % (marked, exact, missing, (n // 16) ** 3), flush=True)
+    smap.copy_(kept)
     pts = torch.empty((synth.ROWS, synth.COLS, 4), dtype=torch.float32, device="cuda")
     nrm = torch.empty_like(pts)
-    for view in (0, 37, 100, 222):
+    for view in (0, 37, 100, 150, 222):
         _, R_v2c, t_v2c = synth.scene_s2(view)
         R = np.ascontiguousarray(R_v2c.T)
         t = (-(R_v2c.astype(np.float64).T @ t_v2c.astype(np.float64))).astype(np.float32)
-        call = lambda: ctx.raycast_points(desc, R.reshape(-1), t, R_v2c.reshape(-1), synth.INTR, pts.data_ptr(),  # noqa: E731
-                                          synth.COLS * 16, nrm.data_ptr(), synth.COLS * 16, synth.ROWS, synth.COLS)
-        for _ in range(3):
-            call()
-        ctx.set_option("kernel_timing", 1)
-        for _ in range(args.reps):
-            call()
-        ms, k = ctx.kernel_time()
-        ctx.set_option("kernel_timing", 0)
-        hits = int((~torch.isnan(pts[..., 0])).sum().item())
-        print("view %3d: raycast_kernel %.4f ms (mean of %d), %d hits of %d rays" % (view, ms / k, k, hits,
-                                                                                  synth.ROWS * synth.COLS), flush=True)
+        results = []
+        for name, d in (("no map", plain), ("map", desc)):
+            call = lambda: ctx.raycast_points(d, R.reshape(-1), t, R_v2c.reshape(-1), synth.INTR, pts.data_ptr(),  # noqa: E731
+                                              synth.COLS * 16, nrm.data_ptr(), synth.COLS * 16, synth.ROWS, synth.COLS)
+            for _ in range(3):
+                call()
+            ctx.set_option("kernel_timing", 1)
+            for _ in range(args.reps):
+                call()
+            ms, k = ctx.kernel_time()
+            ctx.set_option("kernel_timing", 0)
+            hits = int((~torch.isnan(pts[..., 0])).sum().item())
+            results.append((pts.clone(), nrm.clone()))
+            print("view %3d %-6s: raycast_kernel %.4f ms (mean of %d), %d hits of %d rays" % (view, name, ms / k, k, hits,
+                                                                                           synth.ROWS * synth.COLS), flush=True)
+        same = all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(results[0], results[1]))
+        print("view %3d: maps with and without the surface map are %s" % (view, "bit-identical" if same else "DIFFERENT"), flush=True)
     ctx.close()
 
 

@@ -16,7 +16,7 @@ EXPORTS = [
     "yakhip_ctx_kernel_time", "yakhip_ctx_kernel_times", "yakhip_ctx_brick_stats", "yakhip_selftest_division",
     "yakhip_malloc", "yakhip_malloc_pitch", "yakhip_free", "yakhip_upload", "yakhip_download",
     "yakhip_upload_2d", "yakhip_download_2d", "yakhip_copy", "yakhip_copy_2d",
-    "yakhip_clear_volume", "yakhip_compute_dists", "yakhip_integrate", "yakhip_integrate_static",
+    "yakhip_clear_volume", "yakhip_surface_map_bytes", "yakhip_surface_map_rebuild", "yakhip_compute_dists", "yakhip_integrate", "yakhip_integrate_static",
     "yakhip_integrate_batch",
     "yakhip_raycast_points", "yakhip_raycast_depth", "yakhip_raycast_slab", "yakhip_raycast_resolve", "yakhip_raycast_halo",
     "yakhip_bilateral_filter", "yakhip_truncate_depth", "yakhip_depth_pyramid", "yakhip_compute_points_normals",
@@ -48,6 +48,7 @@ class VolumeDesc(C.Structure):
         ("voxel_size", C.c_float * 3),
         ("trunc_dist", C.c_float),
         ("max_weight", C.c_int),
+        ("surface_map", C.c_void_p),
     ]
 
 
@@ -111,6 +112,8 @@ def load():
         "yakhip_copy": [vp, vp, vp, sz],
         "yakhip_copy_2d": [vp, vp, sz, vp, sz, sz, sz],
         "yakhip_clear_volume": [vp, volp],
+        "yakhip_surface_map_bytes": [volp, C.POINTER(sz)],
+        "yakhip_surface_map_rebuild": [vp, volp],
         "yakhip_compute_dists": [vp, vp, sz, vp, sz, i, i, fp],
         "yakhip_integrate": [vp, volp, vp, sz, i, i, fp, fp, fp],
         "yakhip_integrate_static": [vp, volp, vp, sz, i, i, fp, fp, fp],
@@ -241,6 +244,10 @@ class Context:
     # ---- hot path; pointers are raw device addresses (ints) ----
     def clear_volume(self, vol):
         _chk(load().yakhip_clear_volume(self._h, C.byref(vol)))
+
+    def surface_map_rebuild(self, vol):
+        """vol.surface_map <- the bricks of the slab that hold a negative voxel (after voxels were written by other means)."""
+        _chk(load().yakhip_surface_map_rebuild(self._h, C.byref(vol)))
 
     def compute_dists(self, depth_ptr, depth_pitch, dists_ptr, dists_pitch, rows, cols, intr):
         _chk(load().yakhip_compute_dists(self._h, C.c_void_p(depth_ptr), depth_pitch, C.c_void_p(dists_ptr),
@@ -499,8 +506,17 @@ def raycast_halo(vol, step_factor=0.75, gradient_delta_factor=0.5):
     return n.value
 
 
-def volume_desc(data_ptr, dims, voxel_size, trunc_dist, max_weight, z0=0, z1=None):
+def surface_map_bytes(vol):
+    """Bytes of the surface map of the slab `vol` (one bit per 16^3 brick, yakhip.h)."""
+    n = C.c_size_t(0)
+    _chk(load().yakhip_surface_map_bytes(C.byref(vol), C.byref(n)))
+    return n.value
+
+
+def volume_desc(data_ptr, dims, voxel_size, trunc_dist, max_weight, z0=0, z1=None, surface_map=None):
+    """surface_map: device pointer of surface_map_bytes() bytes, or None (ray casts then fetch every sample)."""
     v = VolumeDesc()
+    v.surface_map = surface_map
     v.data = data_ptr
     v.dims[:] = [int(d) for d in dims]
     v.z0 = int(z0)

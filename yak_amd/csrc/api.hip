@@ -70,7 +70,15 @@ static int check_volume(const yakhip_volume* v)
   // in-plane offsets are 32-bit on the device; a slab is addressed with 64-bit offsets
   if ((uint64_t)v->dims[0] * (uint64_t)v->dims[1] > 0x7fffffffull)
     return fail(YAKHIP_ERANGE, "volume: one z layer exceeds 2^31 voxels");
+  if ((uintptr_t)v->surface_map % 4 != 0)
+    return fail(YAKHIP_EALIGN, "volume: surface map pointer must be 4-byte aligned");
   return 0;
+}
+
+// 32-bit words of a slab's surface map (yakhip.h): one bit per 16^3 brick of its layers
+static size_t surface_map_words(const yakhip_volume* v)
+{
+  return surface_brick_words(v->dims[0], v->dims[1], v->z1 - v->z0);
 }
 }  // namespace yakhip
 
@@ -125,6 +133,7 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->group_test = 1;
   ctx->brick_test = 1;
   ctx->chunk_order = -1;
+  ctx->surface_skip = 1;
   ctx->chunk_min = 0;
   ctx->chunk_ramp = 0;
   ctx->checkpoint = 1;
@@ -275,6 +284,11 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
   if (strcmp(key, "chunk_order") == 0)
   {
     ctx->chunk_order = (int)value;
+    return 0;
+  }
+  if (strcmp(key, "surface_skip") == 0)
+  {
+    ctx->surface_skip = value != 0;
     return 0;
   }
   if (strcmp(key, "chunk_min") == 0)
@@ -642,7 +656,33 @@ int yakhip_clear_volume(yakhip_ctx* ctx, const yakhip_volume* vol)
   if ((rc = check_volume(vol)) != 0)
     return rc;
   const size_t n = (size_t)vol->dims[0] * (size_t)vol->dims[1] * (size_t)(vol->z1 - vol->z0);
+  if (vol->surface_map)
+    YAKHIP_TRY(hipMemsetAsync(vol->surface_map, 0, surface_map_words(vol) * 4u, ctx->stream));
   return launch_clear(ctx, (uint32_t*)vol->data, n);
+}
+
+int yakhip_surface_map_bytes(const yakhip_volume* vol, size_t* bytes)
+{
+  int rc = check_volume(vol);
+  if (rc != 0)
+    return rc;
+  if (!bytes)
+    return fail(YAKHIP_EINVAL, "surface_map_bytes: null output");
+  *bytes = surface_map_words(vol) * 4u;
+  return 0;
+}
+
+int yakhip_surface_map_rebuild(yakhip_ctx* ctx, const yakhip_volume* vol)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_volume(vol)) != 0)
+    return rc;
+  if (!vol->surface_map)
+    return fail(YAKHIP_EINVAL, "surface_map_rebuild: the volume has no surface map");
+  return launch_surface_scan(ctx, (const uint32_t*)vol->data, vol->dims[0], vol->dims[1], vol->z1 - vol->z0,
+                             (uint32_t*)vol->surface_map);
 }
 
 static int check_image(const char* who, const void* ptr, size_t pitch, int rows, int cols, size_t elem)
@@ -693,6 +733,9 @@ static int fill_integrate_params(IntegrateParams& p, const yakhip_volume* vol, c
     return fail(YAKHIP_EINVAL, "integrate: trunc_dist must be positive");
 
   p.vol = (uint32_t*)vol->data;
+  p.bricks = (uint32_t*)vol->surface_map;
+  p.bricks_x = (vol->dims[0] + 15) >> 4;
+  p.bricks_y = (vol->dims[1] + 15) >> 4;
   p.dists = (const uint8_t*)dists_dev;
   p.thr = nullptr;  // thr, coarse, cw/ch and the grp_* constants are filled by the launcher
   p.coarse = nullptr;
@@ -846,6 +889,11 @@ static int raycast_common(yakhip_ctx* ctx, const yakhip_volume* vol, const float
   p.depth_pitch = (uint32_t)depth_pitch;
   p.keys = (uint8_t*)keys, p.keys_pitch = (uint32_t)keys_pitch;
   p.z_base = vol->z0, p.z_held = vol->z1 - vol->z0, p.z_own0 = z_own0, p.z_own1 = z_own1;
+  p.skip = (const uint32_t*)vol->surface_map;
+  p.skip_x = (vol->dims[0] + 15) >> 4, p.skip_y = (vol->dims[1] + 15) >> 4;
+  const size_t words = surface_brick_words(vol->dims[0], vol->dims[1], vol->z1 - vol->z0);
+  p.skip_words = words <= 0x3fffffffull ? (int)words : 0x3fffffff;
+  p.vol_bytes = (unsigned long long)vol->dims[0] * (unsigned long long)vol->dims[1] * (unsigned long long)(vol->z1 - vol->z0) * 4ull;
   return launch_raycast(ctx, p);
 }
 
@@ -924,7 +972,7 @@ int yakhip_raycast_resolve(yakhip_ctx* ctx, const yakhip_volume* vol, int z_own0
     return fail(YAKHIP_EINVAL, "raycast_resolve: own layers [%d, %d) of held [%d, %d) leave less than the %d halo layers needed",
                 z_own0, z_own1, vol->z0, vol->z1, h);
 
-  RaycastParams p;
+  RaycastParams p = {};
   memset(&p, 0, sizeof(p));
   p.vol = (const uint32_t*)vol->data;
   p.X = vol->dims[0], p.Y = vol->dims[1], p.Z = vol->dims[2];
@@ -979,7 +1027,7 @@ int yakhip_extract_normals(yakhip_ctx* ctx, const yakhip_volume* vol, const void
     return fail(YAKHIP_EINVAL, "extract_normals: null buffer");
   if ((((uintptr_t)points_dev | (uintptr_t)normals_dev) & 15) != 0)
     return fail(YAKHIP_EALIGN, "extract_normals: buffers not 16-byte aligned");
-  RaycastParams p;
+  RaycastParams p = {};
   memset(&p, 0, sizeof(p));
   p.vol = (const uint32_t*)vol->data;
   p.X = vol->dims[0], p.Y = vol->dims[1], p.Z = vol->dims[2];

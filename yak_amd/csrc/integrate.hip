@@ -481,7 +481,7 @@ __device__ __forceinline__ void buf_store(typename Vec<VX>::type v, rsrc_t rs, u
 // (hit), which of those with a measurement of exactly 1.0 (unit), and the measurement (tsdf).
 template <int VX>
 __device__ __forceinline__ void settle(const IntegrateParams& p, const Pos<VX>& c, const Probe<VX>& pr, mask_t live_m,
-                                       mask_t (&hit)[VX], mask_t (&unit)[VX], float (&tsdf)[VX])
+                                       mask_t (&hit)[VX], mask_t (&unit)[VX], float (&tsdf)[VX], mask_t& negative)
 {
 #pragma unroll
   for (int v = 0; v < VX; ++v)
@@ -520,6 +520,7 @@ __device__ __forceinline__ void settle(const IntegrateParams& p, const Pos<VX>& 
         tsdf[v] = lanes(in_band) ? t : tsdf[v];
         hit[v] |= in_band;
         unit[v] |= in_band & ballot(t == 1.f);
+        negative |= in_band & ballot(t < 0.f);  // (surface map: the only way a voxel turns negative)
         slow_any |= rare[v] & pr.slow[v];
       }
       if (slow_any != 0)  // wave-uniform: vc.z outside the Markstein range, practically never
@@ -545,6 +546,7 @@ __device__ __forceinline__ void settle(const IntegrateParams& p, const Pos<VX>& 
         {
           hit[v] |= ballot(exact_hit[v]);
           unit[v] |= ballot(exact_hit[v] && tsdf[v] == 1.f);
+          negative |= ballot(exact_hit[v] && tsdf[v] < 0.f);
         }
       }
     }
@@ -589,13 +591,13 @@ template <int VX, bool NT>
 __device__ __forceinline__ void update(const IntegrateParams& p, const Pos<VX>& c, const Probe<VX>& pr,
                                        typename Vec<VX>::type& buf, mask_t& buf_valid, rsrc_t rs, uint32_t voff,
                                        uint32_t soff, uint32_t layer_bytes, bool live, bool ahead_ok,
-                                       uint32_t max_w_hi)
+                                       uint32_t max_w_hi, mask_t& band)
 {
   typedef typename Vec<VX>::type vec_t;
   mask_t hit[VX], unit[VX];
   float tsdf[VX];
   mask_t hit_any = 0;
-  settle<VX>(p, c, pr, live ? ~0ull : 0ull, hit, unit, tsdf);
+  settle<VX>(p, c, pr, live ? ~0ull : 0ull, hit, unit, tsdf, band);
 #pragma unroll
   for (int v = 0; v < VX; ++v)
     hit_any |= hit[v];
@@ -623,6 +625,45 @@ __device__ __forceinline__ void update(const IntegrateParams& p, const Pos<VX>& 
   // update the layer two steps on (this buffer's next use); fetch it now
   buf_valid = ahead_ok ? hit_any : 0;
   buf = buf_load<VX, NT>(rs, lanes(buf_valid) ? voff : kNoAccess, ahead_ok ? soff + 2u * layer_bytes : 0u);
+}
+
+// ---- surface map (yakhip_volume.surface_map) --------------------------------------------------------
+// One bit per brick of 16 x 16 x 16 voxels of the slab: set = the brick may hold a voxel with a negative tsdf.
+// The ray cast skips the fetches of samples in bricks whose bit is clear (raycast.hip).  A voxel can only turn
+// negative when a negative measurement is folded into it (an average of values >= 0 is >= 0), and measurements
+// are negative only behind the surface inside the truncation band: the walk collects the lanes that took one
+// (`band`, a wave mask in SGPRs, updated on the band path of settle() only) and sets their brick's bit when it
+// leaves the brick's layers.
+// Bits are only ever set here; yakhip_clear_volume clears them, yakhip_surface_map_rebuild recomputes them.
+constexpr int kBrickShift = 4;  // YAKHIP_SURFACE_BRICK = 16
+
+__device__ __forceinline__ void mark_bricks(const IntegrateParams& p, mask_t band, int x0, int y, int z_rel)
+{
+  if (band == 0)  // wave-uniform
+    return;
+  if (lanes(band))
+  {
+    const uint32_t b = (uint32_t)(x0 >> kBrickShift) +
+                       (uint32_t)p.bricks_x * ((uint32_t)(y >> kBrickShift) + (uint32_t)p.bricks_y * (uint32_t)(z_rel >> kBrickShift));
+    uint32_t* word = p.bricks + (b >> 5);
+    const uint32_t bit = 1u << (b & 31u);
+    if (!(__builtin_nontemporal_load(word) & bit))  // (a stale line only costs a redundant atomic)
+      atomicOr(word, bit);
+  }
+}
+
+// after the layers z, z + 1 (z - z0 even or odd) have been settled: flush `band` if the next layer starts another brick
+// or the walk ends
+__device__ __forceinline__ void flush_bricks(const IntegrateParams& p, mask_t& band, int x0, int y, int z, int step, int end)
+{
+  const int r = z - p.z0;
+  if (((r + step) >> kBrickShift) != (r >> kBrickShift) || z + step >= end)
+  {
+    mark_bricks(p, band, x0, y, r);
+    if (step > 1 && ((r + step - 1) >> kBrickShift) != (r >> kBrickShift) && z + step - 1 < end)
+      mark_bricks(p, band, x0, y, r + step - 1);  // (an odd chunk start: the pair of layers straddles two bricks)
+    band = 0;
+  }
 }
 
 // Which voxels of a layer a lane owns.  tile_shift == 6: lanes in layer order, a wave = 64 * VX voxels of
@@ -964,17 +1005,20 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
   vec_t bufB = buf_load<VX, NT>(rs, validB ? voff : kNoAccess, validB ? layer_bytes : 0u);
   __builtin_amdgcn_sched_barrier(0);
   uint32_t soff = 0;
+  mask_t band = 0;  // lanes that folded a negative measurement into a voxel since the last flush (surface map)
   for (int z = ws; z < we; z += 2, soff += 2u * layer_bytes)
   {
     // layer z lives in set A, layer z+1 in set B.  Stage 1 runs one layer ahead and is not guarded at
     // the walk's end: a projection past we reads valid threshold texels and is discarded.
     advance<VX>(A, B, sx, sy, sz);
     stage1<VX>(p, B, PB, coarse_lds, active, fx2, fy2, cx2, cy2);
-    update<VX, NT>(p, A, PA, bufA, validA, rs, voff, soff, layer_bytes, true, z + 2 < we, max_w_hi);
+    update<VX, NT>(p, A, PA, bufA, validA, rs, voff, soff, layer_bytes, true, z + 2 < we, max_w_hi, band);
     advance<VX>(B, A, sx, sy, sz);
     stage1<VX>(p, A, PA, coarse_lds, active, fx2, fy2, cx2, cy2);
     update<VX, NT>(p, B, PB, bufB, validB, rs, voff, soff + layer_bytes, layer_bytes, z + 1 < we, z + 3 < we,
-                   max_w_hi);
+                   max_w_hi, band);
+    if (p.bricks)
+      flush_bricks(p, band, x0, y, z, 2, we);
   }
 }
 
@@ -1448,6 +1492,7 @@ __global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchPara
                                                       (uint32_t)(ze - zs) * layer_bytes, 0x00020000);
   const uint32_t voff = elem * 4u;
 
+  mask_t band = 0;      // (surface map, see the single-frame kernel)
   mask_t have = ~0ull;  // lanes whose `cur` holds this layer's voxels
   vec_t cur = buf_load<VX, NT>(rs, voff, 0u);
   uint32_t soff = 0;
@@ -1477,7 +1522,7 @@ __global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchPara
         const f32x2 fx2 = { f.fx, f.fx }, fy2 = { f.fy, f.fy }, cx2 = { f.cx, f.cx }, cy2 = { f.cy, f.cy };
         Probe<VX> pr;
         stage1<VX>(f, pos[k], pr, coarse_lds + k * cells, active, fx2, fy2, cx2, cy2);
-        settle<VX>(f, pos[k], pr, ~0ull, hit, unit, tsdf);
+        settle<VX>(f, pos[k], pr, ~0ull, hit, unit, tsdf, band);
         const float zx = f.R[2] * p.vsz, zy = f.R[5] * p.vsz, zz = f.R[8] * p.vsz;
         advance<VX>(pos[k], pos[k], f32x2{ zx, zx }, f32x2{ zy, zy }, f32x2{ zz, zz });
       }
@@ -1505,6 +1550,8 @@ __global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchPara
     // look-ahead: a lane that updated this layer very likely updates the next one
     have = z + 1 < ze ? any : 0;
     cur = buf_load<VX, NT>(rs, lanes(have) ? voff : kNoAccess, z + 1 < ze ? soff + layer_bytes : 0u);
+    if (p.bricks)
+      flush_bricks(p, band, x0, y, z, 1, ze);
   }
 }
 

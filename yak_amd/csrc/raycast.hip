@@ -31,6 +31,7 @@ namespace yakhip
 namespace
 {
 constexpr int kUnroll = 4;
+constexpr int kMaxSkipWords = 8192;  // 32 KiB of LDS: 2^18 bricks, e.g. 1024^3 voxels or a 2048 x 2048 x 256 slab
 
 template <bool IDX32>
 __device__ __forceinline__ float voxel_tsdf(const RaycastParams& p, int x, int y, int z)
@@ -81,6 +82,40 @@ __device__ __forceinline__ float fetch_tsdf(const RaycastParams& p, float px, fl
   if constexpr (SLAB)
     owned = z >= p.z_own0 && z < p.z_own1;
   return voxel_tsdf_at<IDX32, SLAB>(p, x, y, z, held);
+}
+
+// The same with the surface map (one bit per 16^3 brick of the held layers, a copy in LDS): a sample in a brick
+// that holds no negative voxel is not fetched.  It reads as +0 with `skipped` set: its true value is >= 0, which
+// is all the march needs to know unless the other sample of its pair is negative -- then the march fetches it
+// after all.  No branch: the voxel is read through a buffer descriptor over the held layers, and a lane that
+// skips passes an offset beyond it (2^31), for which the hardware returns 0 without touching memory.
+constexpr int kSkipShift = 4;  // YAKHIP_SURFACE_BRICK = 16
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+template <bool SLAB>
+__device__ __forceinline__ float fetch_tsdf_skip(const RaycastParams& p, rsrc_t rs, const uint32_t* map_lds, float px, float py,
+                                                 float pz, bool& owned, bool& held, bool& skipped)
+{
+  const int x = clampi((int)__builtin_rintf(px * p.ivx), p.X - 1);
+  const int y = clampi((int)__builtin_rintf(py * p.ivy), p.Y - 1);
+  const int z = clampi((int)__builtin_rintf(pz * p.ivz), p.Z - 1);
+  int zl = z;
+  bool in = true;
+  if constexpr (SLAB)
+  {
+    owned = z >= p.z_own0 && z < p.z_own1;
+    zl = z - p.z_base;
+    in = (unsigned)zl < (unsigned)p.z_held;
+    held = held && in;
+    zl = in ? zl : 0;
+  }
+  const uint32_t b = (uint32_t)(x >> kSkipShift) +
+                     (uint32_t)p.skip_x * ((uint32_t)(y >> kSkipShift) + (uint32_t)p.skip_y * (uint32_t)(zl >> kSkipShift));
+  const bool marked = (map_lds[b >> 5] >> (b & 31u)) & 1u;
+  skipped = in && !marked;
+  const uint32_t idx = (uint32_t)x + (uint32_t)p.X * ((uint32_t)y + (uint32_t)p.Y * (uint32_t)zl);
+  const uint32_t word = __builtin_amdgcn_raw_buffer_load_b32(rs, in && marked ? idx << 2 : 0x80000000u, 0, 0);
+  return half_bits_to_float(word & 0xffffu);
 }
 
 // tsdf_volume.cu:167-192: trilinear tap, argument in voxel units
@@ -138,7 +173,7 @@ __device__ __forceinline__ void surface_gradient(const RaycastParams& p, float p
   normalize3(gx, gy, gz);
 }
 
-template <bool IDX32, bool SLAB>
+template <bool IDX32, bool SLAB, bool SKIP>
 __global__ __launch_bounds__(256) void raycast_kernel(const RaycastParams p, int tiles_x, int n_tiles, int per_xcd)
 {
   // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; give each XCD a
@@ -147,6 +182,13 @@ __global__ __launch_bounds__(256) void raycast_kernel(const RaycastParams p, int
   const int tile = (bid & 7) * per_xcd + (bid >> 3);
   if (tile >= n_tiles)
     return;
+  extern __shared__ uint32_t map_lds[];
+  if constexpr (SKIP)
+  {
+    for (int i = (int)threadIdx.x; i < p.skip_words; i += 256)
+      map_lds[i] = p.skip[i];
+    __syncthreads();
+  }
   const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
   const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
   const int x = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
@@ -189,12 +231,18 @@ __global__ __launch_bounds__(256) void raycast_kernel(const RaycastParams p, int
   int pair = 0;
   if (state == 0)
   {
-    bool own_next = true, scratch = true;
-    float tsdf_next = fetch_tsdf<IDX32, SLAB>(p, nx, ny, nz, own_next, scratch);
+    bool own_next = true, scratch = true, skip_next = false;
+    float tsdf_next;
+    // (SKIP only; the launcher takes this variant only for held layers below 2 GiB)
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.vol), 0, (uint32_t)p.vol_bytes, 0x00020000);
+    if constexpr (SKIP)
+      tsdf_next = fetch_tsdf_skip<SLAB>(p, rs, map_lds, nx, ny, nz, own_next, scratch, skip_next);
+    else
+      tsdf_next = fetch_tsdf<IDX32, SLAB>(p, nx, ny, nz, own_next, scratch);
     while (state == 0)
     {
       float qx[kUnroll], qy[kUnroll], qz[kUnroll], f[kUnroll];
-      bool own[kUnroll], held[kUnroll];
+      bool own[kUnroll], held[kUnroll], skip[kUnroll];
       float ax = nx, ay = ny, az = nz;
 #pragma unroll
       for (int k = 0; k < kUnroll; ++k)
@@ -203,16 +251,31 @@ __global__ __launch_bounds__(256) void raycast_kernel(const RaycastParams p, int
         ay += sy;
         az += sz;
         qx[k] = ax, qy[k] = ay, qz[k] = az;
-        own[k] = true, held[k] = true;
-        f[k] = fetch_tsdf<IDX32, SLAB>(p, ax, ay, az, own[k], held[k]);
+        own[k] = true, held[k] = true, skip[k] = false;
+        if constexpr (SKIP)
+          f[k] = fetch_tsdf_skip<SLAB>(p, rs, map_lds, ax, ay, az, own[k], held[k], skip[k]);
+        else
+          f[k] = fetch_tsdf<IDX32, SLAB>(p, ax, ay, az, own[k], held[k]);
       }
       float cx = nx, cy = ny, cz = nz, fc = tsdf_next;
-      bool own_c = own_next;
+      bool own_c = own_next, skip_c = skip_next;
 #pragma unroll
       for (int k = 0; k < kUnroll; ++k)
       {
         if (state == 0)
         {
+          if constexpr (SKIP)
+          {
+            // a skipped sample is >= 0; its value matters only beside a negative one (tsdf_volume.cu:326-331)
+            bool o = true, h = true;
+            if (skip_c && f[k] < 0.f)
+              fc = fetch_tsdf<IDX32, SLAB>(p, cx, cy, cz, o, h);
+            if (skip[k] && fc < 0.f)
+            {
+              f[k] = fetch_tsdf<IDX32, SLAB>(p, qx[k], qy[k], qz[k], o, h);
+              skip[k] = false;
+            }
+          }
           if (!(tcurr < tmax))
             state = 2;
           else if (own_c && fc < 0.f && f[k] > 0.f)
@@ -229,9 +292,9 @@ __global__ __launch_bounds__(256) void raycast_kernel(const RaycastParams p, int
             ++pair;
           }
         }
-        cx = qx[k], cy = qy[k], cz = qz[k], fc = f[k], own_c = own[k];
+        cx = qx[k], cy = qy[k], cz = qz[k], fc = f[k], own_c = own[k], skip_c = skip[k];
       }
-      nx = cx, ny = cy, nz = cz, tsdf_next = fc, own_next = own_c;
+      nx = cx, ny = cy, nz = cz, tsdf_next = fc, own_next = own_c, skip_next = skip_c;
     }
   }
 
@@ -377,7 +440,48 @@ __global__ __launch_bounds__(256) void extract_normals_kernel(const RaycastParam
   }
   out[idx] = make_float4(nx, ny, nz, 0.f);
 }
+// yakhip_surface_map_rebuild: the surface map of a slab from its voxels.  One workgroup per brick: thread t reads
+// the 16 voxels of row (y = t & 15, z = t >> 4) of the brick; a voxel is negative if its half has the sign bit
+// and a non-zero magnitude.
+__global__ __launch_bounds__(256) void surface_scan_kernel(const uint32_t* vol, int X, int Y, int layers, int bricks_x,
+                                                           int bricks_y, uint32_t* map)
+{
+  const uint32_t b = blockIdx.x;
+  const int bx = (int)(b % (uint32_t)bricks_x), by = (int)((b / (uint32_t)bricks_x) % (uint32_t)bricks_y),
+            bz = (int)(b / ((uint32_t)bricks_x * (uint32_t)bricks_y));
+  const int y = by * 16 + ((int)threadIdx.x & 15), z = bz * 16 + ((int)threadIdx.x >> 4);
+  bool neg = false;
+  if (y < Y && z < layers)
+  {
+    const uint32_t* row = vol + ((size_t)z * (size_t)Y + (size_t)y) * (size_t)X;
+    for (int x = bx * 16; x < min(bx * 16 + 16, X); ++x)
+    {
+      const uint32_t w = row[x];
+      neg = neg || ((w & 0x8000u) && (w & 0x7fffu));
+    }
+  }
+  __shared__ int any;
+  if (threadIdx.x == 0)
+    any = 0;
+  __syncthreads();
+  if (__builtin_amdgcn_ballot_w64(neg) != 0 && (threadIdx.x & 63u) == 0)
+    any = 1;
+  __syncthreads();
+  if (threadIdx.x == 0 && any)
+    atomicOr(map + (b >> 5), 1u << (b & 31u));
+}
 }  // namespace
+
+int launch_surface_scan(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int layers, uint32_t* map)
+{
+  const int bx = (X + 15) >> 4, by = (Y + 15) >> 4, bz = (layers + 15) >> 4;
+  const unsigned long long bricks = (unsigned long long)bx * by * bz;
+  if (bricks > 0x7fffffffull)
+    return fail(YAKHIP_ERANGE, "surface_map_rebuild: too many bricks");
+  YAKHIP_TRY(hipMemsetAsync(map, 0, surface_brick_words(X, Y, layers) * 4u, ctx->stream));
+  hipLaunchKernelGGL(surface_scan_kernel, dim3((unsigned)bricks), dim3(256), 0, ctx->stream, vol, X, Y, layers, bx, by, map);
+  return check(hipGetLastError(), "surface_scan_kernel launch");
+}
 
 int launch_extract_normals(yakhip_ctx* ctx, const RaycastParams& p, const void* points, void* normals, unsigned long long n)
 {
@@ -426,14 +530,26 @@ int launch_raycast(yakhip_ctx* ctx, const RaycastParams& p)
   int rc = timing_begin(ctx, &ev);
   if (rc != 0)
     return rc;
+  // the surface map travels in LDS: volumes whose map is too large for that are marched without it
+  const bool skip = p.skip != nullptr && p.skip_words <= kMaxSkipWords && p.vol_bytes < 0x80000000ull && ctx->surface_skip;
+  const size_t lds = skip ? (size_t)p.skip_words * 4u : 0;
+#define YAK_RAYCAST_LAUNCH(I, S)                                                                                    \
+  do                                                                                                               \
+  {                                                                                                                \
+    if (skip)                                                                                                      \
+      hipLaunchKernelGGL((raycast_kernel<I, S, true>), grid, dim3(256), lds, ctx->stream, p, tiles_x, n_tiles, per_xcd);  \
+    else                                                                                                           \
+      hipLaunchKernelGGL((raycast_kernel<I, S, false>), grid, dim3(256), lds, ctx->stream, p, tiles_x, n_tiles, per_xcd); \
+  } while (0)
   if (slab && idx32)
-    hipLaunchKernelGGL((raycast_kernel<true, true>), grid, dim3(256), 0, ctx->stream, p, tiles_x, n_tiles, per_xcd);
+    YAK_RAYCAST_LAUNCH(true, true);
   else if (slab)
-    hipLaunchKernelGGL((raycast_kernel<false, true>), grid, dim3(256), 0, ctx->stream, p, tiles_x, n_tiles, per_xcd);
+    YAK_RAYCAST_LAUNCH(false, true);
   else if (idx32)
-    hipLaunchKernelGGL((raycast_kernel<true, false>), grid, dim3(256), 0, ctx->stream, p, tiles_x, n_tiles, per_xcd);
+    YAK_RAYCAST_LAUNCH(true, false);
   else
-    hipLaunchKernelGGL((raycast_kernel<false, false>), grid, dim3(256), 0, ctx->stream, p, tiles_x, n_tiles, per_xcd);
+    YAK_RAYCAST_LAUNCH(false, false);
+#undef YAK_RAYCAST_LAUNCH
   if ((rc = timing_end(ctx, ev)) != 0)
     return rc;
   return check(hipGetLastError(), "raycast_kernel launch");

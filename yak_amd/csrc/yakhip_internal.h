@@ -22,6 +22,7 @@ struct yakhip_ctx
   int chunk_order;     // -1 automatic; 0 ascending, 1 shallow / deep in turn, 3 deepest first (tuning)
   int chunk_min;       // 0 automatic; shortest chunk of a graded table, layers (tuning)
   int chunk_ramp;      // 0 automatic (6); a chunk starting at layer zs is about zs / ramp layers long; -1: all chunks alike (tuning)
+  int surface_skip;    // the ray cast consults a volume's surface map (default) / ignores it
   int brick_test;      // classify whole bricks (dead / front / mixed) before walking them (default) / off
   int checkpoint;      // deep slabs start from closed-form column positions (default) / replay from layer 0
   int tile_shift;      // 0 = default wave footprint, else 3..6 (tuning)
@@ -81,6 +82,8 @@ struct IntegrateParams
   const float* cellmin;  // brick test: min of A2 / max of the B2 word over each 16 x 16 pixel cell, ccw x cch cells
   const float* cellmax;
   int ccw, cch;
+  uint32_t* bricks;      // nullptr, or the slab's surface map: one bit per 16^3 brick, bricks_x x bricks_y x layers / 16
+  int bricks_x, bricks_y;
   uint32_t* brick_stats; // nullptr, or counters {mixed, dead, front} of classified wave bricks ("brick_stats" option)
   int brick_enable;      // classify each workgroup's brick (x-y tile times z-chunk) before walking it
   float brick_eps;       // bound on |replayed fp32 position - ideal position| per camera coordinate (metres)
@@ -136,7 +139,18 @@ struct RaycastParams
   uint8_t* keys;
   uint32_t keys_pitch;
   int z_base, z_held, z_own0, z_own1;
+  // surface map of the held layers (yakhip_volume.surface_map) or nullptr: one bit per 16^3 brick, skip_x x skip_y
+  // bricks per brick layer, skip_words 32-bit words in all
+  const uint32_t* skip;
+  int skip_x, skip_y, skip_words;  // bricks per row / column, 32-bit words
+  unsigned long long vol_bytes;    // bytes of the held layers
 };
+
+// 32-bit words of a slab's surface map (yakhip.h): one bit per 16^3 brick of its layers
+inline size_t surface_brick_words(int X, int Y, int layers)
+{
+  return ((size_t)((X + 15) >> 4) * (size_t)((Y + 15) >> 4) * (size_t)((layers + 15) >> 4) + 31u) / 32u;
+}
 
 // use_static: thresholds / checkpoints go to the file-scope array instead of context-owned buffers, and the
 // call neither allocates nor creates events (yakhip_integrate_static)
@@ -149,6 +163,7 @@ int launch_raycast(yakhip_ctx* ctx, const RaycastParams& p);
 int launch_raycast_resolve(yakhip_ctx* ctx, const RaycastParams& p);
 int launch_extract_normals(yakhip_ctx* ctx, const RaycastParams& p, const void* points, void* normals, unsigned long long n);  // slab mode, after the composite
 int launch_clear(const yakhip_ctx* ctx, uint32_t* data, size_t n_voxels);
+int launch_surface_scan(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int layers, uint32_t* map);  // raycast.hip
 int launch_selftest_division(yakhip_ctx* ctx, unsigned long long counts[4]);
 int launch_compute_dists(const yakhip_ctx* ctx, const uint8_t* depth, size_t depth_pitch, uint8_t* dists,
                          size_t dists_pitch, int rows, int cols, float fx, float fy, float cx, float cy);

@@ -18,7 +18,7 @@ PolygonMesh marchingCubesDevice(const void* volume_dev, int dim_x, int dim_y, in
 {
   using kfusion::cuda::context;
   using kfusion::cuda::error;
-  yakhip_volume v;
+  yakhip_volume v = {};
   v.data = const_cast<void*>(volume_dev);
   v.dims[0] = dim_x, v.dims[1] = dim_y, v.dims[2] = dim_z;
   v.z0 = 0, v.z1 = dim_z;

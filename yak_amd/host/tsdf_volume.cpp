@@ -97,6 +97,7 @@ TsdfVolume::Entry::half TsdfVolume::Entry::float2half(float value)
 TsdfVolume::TsdfVolume(const Vec3i& dims)
   : held_z0_(0)
   , held_z1_(0)
+  , map_stale_(false)
   , data_()
   , trunc_dist_(0.03f)
   , max_weight_(128)
@@ -133,7 +134,7 @@ void TsdfVolume::heldLayers(int& z0, int& z1) const
   ownedLayers(z0, z1);
   if (currentShard().world == 1)
     return;
-  yakhip_volume probe;
+  yakhip_volume probe = {};
   probe.data = (void*)256;  // not looked at
   const Vec3f vsz = getVoxelSize();
   for (int i = 0; i < 3; ++i)
@@ -155,7 +156,7 @@ bool TsdfVolume::ensureSlab()
     return false;
   held_z0_ = z0, held_z1_ = z1;
   data_.create((size_t)dims_[0] * (size_t)dims_[1] * (size_t)(z1 - z0) * sizeof(int));
-  yakhip_volume v;
+  yakhip_volume v = {};
   v.data = data_.ptr<void>();
   const Vec3f vsz = getVoxelSize();
   for (int i = 0; i < 3; ++i)
@@ -164,8 +165,38 @@ bool TsdfVolume::ensureSlab()
     v.voxel_size[i] = vsz[i];
   }
   v.z0 = z0, v.z1 = z1, v.trunc_dist = trunc_dist_, v.max_weight = max_weight_;
+  // the surface map of these layers (include/yakhip.h): integrate keeps it, the ray cast skips free space by it
+  size_t map_bytes = 0;
+  YAK_CHECK(yakhip_surface_map_bytes(&v, &map_bytes));
+  surface_map_.create(map_bytes);
+  v.surface_map = surface_map_.ptr<void>();
   YAK_CHECK(yakhip_clear_volume(context(), &v));
+  map_stale_ = false;
   return true;
+}
+yakhip_volume TsdfVolume::view() const
+{
+  yakhip_volume v = {};
+  v.data = const_cast<void*>(data_.ptr<void>());
+  const Vec3f vsz = getVoxelSize();
+  for (int i = 0; i < 3; ++i)
+  {
+    v.dims[i] = dims_[i];
+    v.voxel_size[i] = vsz[i];
+  }
+  v.z0 = held_z0_, v.z1 = held_z1_, v.trunc_dist = trunc_dist_, v.max_weight = max_weight_;
+  v.surface_map = const_cast<void*>(surface_map_.ptr<void>());
+  return v;
+}
+// Someone may have written voxels behind the class's back (the non-const data() handle, swap): the map is
+// recomputed from the voxels before the next ray cast consults it.
+void TsdfVolume::freshSurfaceMap()
+{
+  if (!map_stale_)
+    return;
+  const yakhip_volume v = view();
+  YAK_CHECK(yakhip_surface_map_rebuild(context(), &v));
+  map_stale_ = false;
 }
 const void* TsdfVolume::ownedData(size_t& voxels) const
 {
@@ -190,7 +221,11 @@ Vec3f TsdfVolume::getVoxelSize() const  // :45-48
   return Vec3f(size_[0] / dims_[0], size_[1] / dims_[1], size_[2] / dims_[2]);
 }
 const CudaData TsdfVolume::data() const { return data_; }
-CudaData TsdfVolume::data() { return data_; }
+CudaData TsdfVolume::data()
+{
+  map_stale_ = true;  // a handle the caller can write through
+  return data_;
+}
 Vec3f TsdfVolume::getSize() const { return size_; }
 void TsdfVolume::setSize(const Vec3f& size)  // :54-58
 {
@@ -216,34 +251,20 @@ float TsdfVolume::getRaycastStepFactor() const { return raycast_step_factor_; }
 void TsdfVolume::setRaycastStepFactor(float factor) { raycast_step_factor_ = factor; }
 float TsdfVolume::getGradientDeltaFactor() const { return gradient_delta_factor_; }
 void TsdfVolume::setGradientDeltaFactor(float factor) { gradient_delta_factor_ = factor; }
-void TsdfVolume::swap(CudaData& data) { data_.swap(data); }
-void TsdfVolume::applyAffine(const Affine3f& affine) { pose_ = affine * pose_; }
-
-namespace
+void TsdfVolume::swap(CudaData& data)
 {
-yakhip_volume make_view(void* data, const Vec3i& dims, const Vec3f& vsz, float trunc, int max_weight, int z0 = 0, int z1 = -1)
-{
-  yakhip_volume v;
-  v.data = data;
-  for (int i = 0; i < 3; ++i)
-  {
-    v.dims[i] = dims[i];
-    v.voxel_size[i] = vsz[i];
-  }
-  v.z0 = z0;
-  v.z1 = z1 < 0 ? dims[2] : z1;
-  v.trunc_dist = trunc;
-  v.max_weight = max_weight;
-  return v;
+  data_.swap(data);
+  map_stale_ = true;
 }
-}  // namespace
+void TsdfVolume::applyAffine(const Affine3f& affine) { pose_ = affine * pose_; }
 
 void TsdfVolume::clear()  // :80-87
 {
   if (ensureSlab())
     return;  // freshly allocated layers are cleared
-  yakhip_volume v = make_view(data_.ptr<void>(), dims_, getVoxelSize(), trunc_dist_, max_weight_, held_z0_, held_z1_);
+  const yakhip_volume v = view();
   YAK_CHECK(yakhip_clear_volume(context(), &v));
+  map_stale_ = false;
 }
 
 // :89-108.  vol2cam = camera_pose^-1 * pose_; the device layer takes it as row-major R and t
@@ -258,7 +279,7 @@ void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_motion_tfo
   const float in[4] = { intr.fx, intr.fy, intr.cx, intr.cy };
   ensureSlab();
   // a rank integrates every layer it holds: its own and, redundantly, the halo (nothing is exchanged)
-  yakhip_volume v = make_view(data_.ptr<void>(), dims_, getVoxelSize(), trunc_dist_, max_weight_, held_z0_, held_z1_);
+  const yakhip_volume v = view();
   YAK_CHECK(yakhip_integrate(context(), &v, dists.ptr(), dists.step(), dists.rows(), dists.cols(), Rf, tf, in));
   YAK_CHECK(yakhip_ctx_synchronize(context()));
 }
@@ -294,7 +315,8 @@ void TsdfVolume::raycast(const Affine3f& camera_pose, const Intr& intr, Depth& d
   const RaycastPose rp = raycast_pose(pose_, camera_pose);
   const float in[4] = { intr.fx, intr.fy, intr.cx, intr.cy };
   ensureSlab();
-  yakhip_volume v = make_view(data_.ptr<void>(), dims_, getVoxelSize(), trunc_dist_, max_weight_, held_z0_, held_z1_);
+  freshSurfaceMap();
+  const yakhip_volume v = view();
   const Shard& sh = currentShard();
   if (sh.world > 1)
   {
@@ -315,7 +337,8 @@ void TsdfVolume::raycast(const Affine3f& camera_pose, const Intr& intr, Cloud& p
   const RaycastPose rp = raycast_pose(pose_, camera_pose);
   const float in[4] = { intr.fx, intr.fy, intr.cx, intr.cy };
   ensureSlab();
-  yakhip_volume v = make_view(data_.ptr<void>(), dims_, getVoxelSize(), trunc_dist_, max_weight_, held_z0_, held_z1_);
+  freshSurfaceMap();
+  const yakhip_volume v = view();
   const Shard& sh = currentShard();
   if (sh.world > 1)
   {
@@ -346,8 +369,7 @@ DeviceArray<Point> TsdfVolume::fetchCloud(DeviceArray<Point>& cloud_buffer) cons
 
   const Mat3f R = pose_.rotation();
   const Vec3f t = pose_.translation();
-  yakhip_volume v = make_view(const_cast<void*>(data_.ptr<void>()), dims_, getVoxelSize(), trunc_dist_, max_weight_, held_z0_,
-                              held_z1_);
+  const yakhip_volume v = view();
   unsigned long long n = 0;
   YAK_CHECK(yakhip_extract_cloud(context(), &v, R.val, t.val, cloud_buffer.ptr(), cloud_buffer.size(), &n));
   const size_t size = n < cloud_buffer.size() ? (size_t)n : cloud_buffer.size();
@@ -361,7 +383,8 @@ void TsdfVolume::fetchNormals(const DeviceArray<Point>& cloud, DeviceArray<Norma
     return;
   const Mat3f R = pose_.rotation(), Rinv = pose_.rotation().inv(cv::DECOMP_SVD);
   const Vec3f t = pose_.translation();
-  yakhip_volume v = make_view(const_cast<void*>(data_.ptr<void>()), dims_, getVoxelSize(), trunc_dist_, max_weight_);
+  yakhip_volume v = view();
+  v.z0 = 0, v.z1 = dims_[2], v.surface_map = nullptr;  // (whole volume only, as before)
   YAK_CHECK(yakhip_extract_normals(context(), &v, cloud.ptr(), cloud.size(), R.val, t.val, Rinv.val,
                                    gradient_delta_factor_, normals.ptr()));
 }

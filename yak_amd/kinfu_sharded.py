@@ -52,6 +52,10 @@ class ShardedKinFu:
         plane = self.dims[0] * self.dims[1]
         self.volume = torch.zeros(plane * (self.held[1] - self.held[0]), dtype=torch.int32, device=device)
         self.desc = capi.volume_desc(self.volume.data_ptr(), self.dims, self.vs, trunc_dist, max_weight, *self.held)
+        # the surface map of the held layers: kept by integrate, consulted by the slab march (include/yakhip.h)
+        self.surface_map = torch.zeros(capi.surface_map_bytes(self.desc) // 4, dtype=torch.int32, device=device)
+        self.desc = capi.volume_desc(self.volume.data_ptr(), self.dims, self.vs, trunc_dist, max_weight, *self.held,
+                                     surface_map=self.surface_map.data_ptr())
         ctx.clear_volume(self.desc)
 
         i16 = lambda r, c: torch.zeros((r, c), dtype=torch.int16, device=device)        # noqa: E731

@@ -19,7 +19,7 @@ def rodrigues(r):
     return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * K @ K
 
 
-def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None, on_system=None):
+def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None, on_system=None, surface_map=True):
     """icp: "device" (yakhip_icp_estimate, one wait per frame), "host" (one blocking linearisation at a time,
     numpy solve) or None (true poses supplied).  scene: the frames, if the caller made them already (a list of
     synth.scene_s2(f, noise_mm=1.0) for f in range(frames)).  Returns a dict with frames/s and per-stage stream times."""
@@ -31,6 +31,9 @@ def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None, on_system=No
     dims, vs, tr = synth.volume_geometry(n)
     vol = torch.zeros(n ** 3, dtype=torch.int32, device="cuda")
     desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT)
+    if surface_map:  # integrate keeps it, the ray cast skips the fetches of free space by it (include/yakhip.h)
+        smap = torch.zeros(capi.surface_map_bytes(desc) // 4, dtype=torch.int32, device="cuda")
+        desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT, surface_map=smap.data_ptr())
     ctx.clear_volume(desc)
     i16 = lambda r, c: torch.empty((r, c), dtype=torch.int16, device="cuda")        # noqa: E731
     f4 = lambda r, c: torch.empty((r, c, 4), dtype=torch.float32, device="cuda")    # noqa: E731
