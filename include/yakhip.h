@@ -107,7 +107,8 @@ const char* yakhip_last_error(void);
  * (marching-cubes tile depth, 0 = auto), "kernel_timing" (0/1, see yakhip_ctx_kernel_time), "chunk_order" (-1 auto, 0 z-chunks dispatched
  * shallow to deep, 1 shallow / deep in turn, 3 deepest first), "chunk_min" / "chunk_ramp" (graded z-chunks of a volume walked from
  * layer 0: a chunk that starts at layer zs is about zs / ramp layers long, at least chunk_min; 0 = auto, ramp -1 = all alike),
- * "surface_skip" (0/1: the ray cast consults / ignores yakhip_volume.surface_map),
+ * "icp_poll" (0/1: yakhip_icp_estimate polls pinned memory for its result / copies and
+ * synchronises), "surface_skip" (0/1: the ray cast consults / ignores yakhip_volume.surface_map),
  * "brick_stats" (0/1, see yakhip_ctx_brick_stats), "composite_capacity" (list slots of yakhip_raycast_sharded's second step, 0 = auto),
  * "zu" (ignored).
  * Unknown key or value -> YAKHIP_EINVAL. */

@@ -149,6 +149,8 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->icp_scratch = nullptr;
   ctx->icp_scratch_bytes = 0;
   ctx->icp_pinned = nullptr;
+  ctx->icp_ticket = 0;
+  ctx->icp_poll = 1;
   ctx->mc_scratch = nullptr;
   ctx->mc_scratch_bytes = 0;
   ctx->mc_pinned = nullptr;
@@ -284,6 +286,11 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
   if (strcmp(key, "chunk_order") == 0)
   {
     ctx->chunk_order = (int)value;
+    return 0;
+  }
+  if (strcmp(key, "icp_poll") == 0)
+  {
+    ctx->icp_poll = value != 0;
     return 0;
   }
   if (strcmp(key, "surface_skip") == 0)

@@ -11,6 +11,8 @@
 // run to run (no float atomics).
 #include "yakhip_internal.h"
 
+#include <chrono>
+
 namespace yakhip
 {
 namespace
@@ -491,8 +493,12 @@ __global__ __launch_bounds__(64) void icp_final_kernel(const float* partial, int
 }
 // The last linearisation of a device-resident estimate has no accumulate launch behind it to finish it:
 // one workgroup does (state_in, partial) -> state_out.
+// host_out / host_ticket (pinned host memory, may be null): the result is also written straight to the host,
+// followed by the call's ticket -- the host polls the ticket instead of waiting for a copy and a stream
+// synchronisation behind this kernel (launch_icp_estimate).
 __global__ __launch_bounds__(1024) void icp_solve_kernel(const float* partial, int n_blocks, const IcpState* state_in,
-                                                         IcpState* state_out)
+                                                         IcpState* state_out, IcpState* host_out, unsigned* host_ticket,
+                                                         unsigned ticket)
 {
   __shared__ float sums[kValues];
   IcpState st;
@@ -502,7 +508,14 @@ __global__ __launch_bounds__(1024) void icp_solve_kernel(const float* partial, i
   if (st.status == 0)
     solve_update(sums, st);
   if (threadIdx.x == 0)
+  {
     *state_out = st;
+    if (host_out)
+    {
+      *host_out = st;
+      __hip_atomic_store(host_ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 }  // namespace
 
@@ -577,7 +590,7 @@ static int icp_scratch(yakhip_ctx* ctx, size_t need)
     ctx->icp_scratch_bytes = need;
   }
   if (!ctx->icp_pinned)
-    YAKHIP_TRY(hipHostMalloc(&ctx->icp_pinned, 256, hipHostMallocDefault));
+    YAKHIP_TRY(hipHostMalloc(&ctx->icp_pinned, 256, hipHostMallocMapped | hipHostMallocCoherent));  // (the device writes to it: icp_solve_kernel)
   return 0;
 }
 
@@ -668,11 +681,36 @@ int launch_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], con
       YAKHIP_TRY(hipGetLastError());
     }
     // j == n_launches: the last launch read slot max(j - 2, 0) and (for j > 1) wrote slot j - 1
+    // The result comes back through pinned memory the last kernel writes itself: its state, then this call's
+    // ticket (release, system scope).  The host polls the ticket -- a few microseconds after the kernel's last
+    // store instead of a copy command, its completion signal and the wake-up of a sleeping thread (measured
+    // in the fusion loop: see DESIGN.md 3.7).  A ticket that does not come within two seconds is looked for
+    // the ordinary way, which also brings any error of the stream to light.
+    IcpState* result = (IcpState*)((char*)ctx->icp_pinned + 128);
+    unsigned* ticket_at = (unsigned*)((char*)ctx->icp_pinned + 192);
+    const bool poll = ctx->icp_poll != 0;
+    const unsigned ticket = ++ctx->icp_ticket;
     hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(1024), 0, ctx->stream, partial[(j - 1) & 1], prev_blocks,
-                       &slots[j - 1], &slots[j]);
+                       &slots[j - 1], &slots[j], poll ? result : nullptr, ticket_at, ticket);
     YAKHIP_TRY(hipGetLastError());
-    YAKHIP_TRY(hipMemcpyAsync(host, &slots[j], sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
-    YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
+    bool arrived = false;
+    if (poll)
+    {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned spins = 1; !arrived; ++spins)
+      {
+        arrived = __atomic_load_n(ticket_at, __ATOMIC_ACQUIRE) == ticket;
+        if (!arrived && (spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2))
+          break;
+      }
+      if (arrived)
+        *host = *result;
+    }
+    if (!arrived)
+    {
+      YAKHIP_TRY(hipMemcpyAsync(host, &slots[j], sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
+      YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
   }
   for (int i = 0; i < 9; ++i)
     R_out[i] = host->R[i];
@@ -769,7 +807,7 @@ int launch_icp_estimate_sharded(yakhip_ctx* ctx, yakhip_comm* comm, const float 
           return rc;
       }
     }
-    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(1024), 0, ctx->stream, sums[(j - 1) & 1], 1, &slots[j - 1], &slots[j]);
+    hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(1024), 0, ctx->stream, sums[(j - 1) & 1], 1, &slots[j - 1], &slots[j], nullptr, nullptr, 0u);
     YAKHIP_TRY(hipGetLastError());
     YAKHIP_TRY(hipMemcpyAsync(host, &slots[j], sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
     YAKHIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -36,7 +36,9 @@ struct yakhip_ctx
   void* static_scratch;  // this device's copy of integrate.hip's file-scope scratch array (yakhip_integrate_static)
   void* icp_scratch;   // ICP: workgroup partials + the reduced 33 values (device)
   size_t icp_scratch_bytes;
-  void* icp_pinned;    // ICP: pinned host mirror of the 33 values
+  void* icp_pinned;    // ICP: pinned host mirror of the 33 values / the state; +128 the state and +192 the ticket icp_solve_kernel writes
+  unsigned icp_ticket; // tickets handed out to yakhip_icp_estimate calls
+  int icp_poll;        // the host polls that ticket (default) / copies and synchronises
   void* mc_scratch;    // marching cubes: tile counts, tile offsets, total (device)
   size_t mc_scratch_bytes;
   void* mc_pinned;     // marching cubes: pinned host copy of the total
