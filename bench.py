@@ -155,7 +155,7 @@ def next_rows(ctx, torch, capi, synth, with_cpu):
                       "rays": rows * cols, "hits_mean": hits // 5, "samples_mean": samples // 5,
                       "roofline": {"bound": "hbm", "achieved": round(rc_bytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
                                    "unit": "GB/s", "frac": round(rc_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                   "algorithmic_bytes": rc_bytes, "traffic": None},
+                                   "algorithmic_bytes": rc_bytes, "traffic": load_traffic("raycast_s2_n1")},
                       "note": "not bound by HBM: the march is one dependent chain of samples per ray (position, nearest voxel, "
                               "sign test); with the surface map the samples of free space are settled from LDS and the kernel "
                               "is bound by VALU issue, without it by gathers of 2 B per 64 B sector"}

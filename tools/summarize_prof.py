@@ -7,7 +7,7 @@ for f in sorted(glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)):
     for row in csv.DictReader(open(f)):
-        agg[row['Kernel_Name'][:60]][row['Counter_Name']].append(float(row['Counter_Value']))
+        agg[row['Kernel_Name'][:100]][row['Counter_Name']].append(float(row['Counter_Value']))
 for k, cs in agg.items():
     print('--', k)
     for c, v in sorted(cs.items()):
