@@ -24,18 +24,51 @@ pytestmark = pytest.mark.gpu
 BRICK = 16
 
 
+def pack_bits(flags):
+    bits = np.zeros(-(-flags.size // 32) * 32, dtype=np.uint64)
+    bits[:flags.size] = flags.reshape(-1)
+    return (bits.reshape(-1, 32) << np.arange(32, dtype=np.uint64)).sum(axis=1).astype(np.uint32)
+
+
+def unpack_bits(words, shape):
+    n = int(np.prod(shape))
+    return ((words[:, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(-1)[:n].astype(bool).reshape(shape)
+
+
+def brick_grid(dims, layers):
+    return -(-layers // BRICK), -(-dims[1] // BRICK), -(-dims[0] // BRICK)       # (bz, by, bx)
+
+
+def cells_of(bricks):
+    """Second level as the library defines it: a cell of 4 x 4 x 4 bricks is marked when a marked brick lies in it
+    or touches it from next door (i.e. within one brick of it)."""
+    bz, by, bx = bricks.shape
+    grown = np.zeros((bz + 2, by + 2, bx + 2), dtype=bool)
+    for dz in range(3):
+        for dy in range(3):
+            for dx in range(3):
+                grown[dz:dz + bz, dy:dy + by, dx:dx + bx] |= bricks                # a brick marks its 26 neighbours' places
+    grown = grown[1:-1, 1:-1, 1:-1]
+    cz, cy, cx = -(-bz // 4), -(-by // 4), -(-bx // 4)
+    pad = np.zeros((cz * 4, cy * 4, cx * 4), dtype=bool)
+    pad[:bz, :by, :bx] = grown
+    return pad.reshape(cz, 4, cy, 4, cx, 4).any(axis=(1, 3, 5))
+
+
 def negative_bricks(vol_host, dims, layers):
-    """Bit array (as the library lays it out) of the bricks of a (layers, Y, X) slab that hold a negative tsdf."""
+    """The bricks of a (layers, Y, X) slab that hold a negative tsdf, as a (bz, by, bx) array."""
     X, Y = dims[0], dims[1]
     w = vol_host.reshape(layers, Y, X)
     neg = ((w & 0x8000) != 0) & ((w & 0x7FFF) != 0)
-    bx, by, bz = -(-X // BRICK), -(-Y // BRICK), -(-layers // BRICK)
+    bz, by, bx = brick_grid(dims, layers)
     pad = np.zeros((bz * BRICK, by * BRICK, bx * BRICK), dtype=bool)
     pad[:layers, :Y, :X] = neg
-    bricks = pad.reshape(bz, BRICK, by, BRICK, bx, BRICK).any(axis=(1, 3, 5)).reshape(-1)
-    bits = np.zeros(-(-bricks.size // 32) * 32, dtype=np.uint64)
-    bits[:bricks.size] = bricks
-    return (bits.reshape(-1, 32) << np.arange(32, dtype=np.uint64)).sum(axis=1).astype(np.uint32), int(bricks.sum())
+    return pad.reshape(bz, BRICK, by, BRICK, bx, BRICK).any(axis=(1, 3, 5))
+
+
+def whole_map(bricks):
+    """Brick words followed by cell words: the layout of yakhip_volume.surface_map."""
+    return np.concatenate([pack_bits(bricks), pack_bits(cells_of(bricks))])
 
 
 def popcount(words):
@@ -98,15 +131,27 @@ def test_integrate_marks_every_brick_that_holds_a_negative_voxel(gpu_ctx, dims, 
     finally:
         gpu_ctx.set_option("z_chunk", 0)
     assert np.array_equal(s.voxels(), want)                       # (the voxels themselves: word for word, as ever)
-    exact, n_exact = negative_bricks(want, dims, s.z1 - s.z0)
+    exact = negative_bricks(want, dims, s.z1 - s.z0)
+    n_exact = int(exact.sum())
     got = s.bits().copy()
+    n_words = pack_bits(exact).size
+    marked = unpack_bits(got[:n_words], exact.shape)
     assert n_exact > 10
-    assert not (exact & ~got).any(), "a brick with a negative voxel is not marked"
+    assert not (exact & ~marked).any(), "a brick with a negative voxel is not marked"
     # marks follow the truncation band, not the frustum (a brick stays marked when later frames, seeing it from the
     # other side, lift its voxels back above zero: hence the factor)
-    assert popcount(got) <= 3 * n_exact + 8
+    assert int(marked.sum()) <= 3 * n_exact + 8
+    # second level: every cell within one brick of a marked brick (the kernels mark the cells of every brick layer
+    # a walk touched, for the lanes that marked a brick during it: a superset, bounded by the chunk length)
+    cells = unpack_bits(got[n_words:], cells_of(marked).shape)
+    assert not (cells_of(marked) & ~cells).any(), "a cell next to a marked brick is not marked"
+    grown = np.zeros_like(marked)
+    for dz in range(-4, 5):                                        # four brick layers either way cover any chunk here
+        lo, hi = max(0, dz), marked.shape[0] + min(0, dz)
+        grown[lo:hi] |= marked[lo - dz:hi - dz]
+    assert not (cells & ~cells_of(grown)).any()
     gpu_ctx.surface_map_rebuild(s.desc)
-    assert np.array_equal(s.bits(), exact)
+    assert np.array_equal(s.bits(), whole_map(exact))
 
 
 def raycast(ctx, desc, R, t, Rinv, intr, rows, cols, depth=False):
@@ -174,8 +219,8 @@ def test_raycast_of_an_uploaded_volume_after_rebuild_and_cameras_inside(gpu_ctx)
     s = Slab(dims, vs, tr)
     s.vol.copy_(torch.from_numpy(vol.view(np.int32)).cuda())
     gpu_ctx.surface_map_rebuild(s.desc)
-    exact, n = negative_bricks(vol, dims, 96)
-    assert n > 10 and np.array_equal(s.bits(), exact)
+    exact = negative_bricks(vol, dims, 96)
+    assert exact.sum() > 10 and np.array_equal(s.bits(), whole_map(exact))
     rows, cols, intr = 120, 160, (145.0, 145.0, 79.5, 59.5)
     rng = np.random.default_rng(11)
     hits = 0
@@ -209,8 +254,8 @@ def test_slab_raycast_with_the_map_is_the_slab_raycast_without_it(gpu_ctx, world
         gpu_ctx.clear_volume(s.desc)
         for dd, (_, R, t) in zip(dev, frames):
             gpu_ctx.integrate(s.desc, dd.data_ptr(), c_ * 2, r_, c_, R.reshape(-1), t, synth.INTR)
-        exact, n = negative_bricks(s.voxels(), dims, h1 - h0)
-        assert n > 5 and not (exact & ~s.bits()).any()
+        exact = negative_bricks(s.voxels(), dims, h1 - h0)
+        assert exact.sum() > 5 and not (whole_map(exact) & ~s.bits()).any()
         for view in (10, 130, 250):
             _, R_v2c, t_v2c = synth.scene_s2(view)
             R, t = cam2vol(R_v2c, t_v2c)
@@ -257,7 +302,7 @@ def test_raycast_512_with_the_map_on_a_volume_fused_on_the_gpu(gpu_ctx):
 def test_surface_map_arguments(gpu_ctx):
     dims, vs, tr = synth.volume_geometry((40, 33, 50))
     s = Slab(dims, vs, tr, 3, 47)
-    assert capi.surface_map_bytes(s.plain) == 4 * -(-(3 * 3 * 3) // 32)
+    assert capi.surface_map_bytes(s.plain) == 4 * (-(-(3 * 3 * 3) // 32) + 1)       # 27 bricks, 1 cell
     with pytest.raises(capi.YakHipError):
         gpu_ctx.surface_map_rebuild(s.plain)                      # no map to rebuild
     bad = capi.volume_desc(s.vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT, 3, 47, surface_map=s.map.data_ptr() + 2)

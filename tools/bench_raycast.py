@@ -14,12 +14,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--no-bands", action="store_true")
+    ap.add_argument("--bands", type=int, default=None)
+    ap.add_argument("--empty", action="store_true", help="ray cast the cleared volume")
     args = ap.parse_args()
     import torch
 
     from yak_amd import capi, synth
 
     ctx = capi.Context(0)
+    if args.no_bands:
+        ctx.set_option("raycast_bands", 0)
+    if args.bands is not None:
+        ctx.set_option("raycast_bands", args.bands)
     n = args.n
     dims, vs, tr = synth.volume_geometry(n)
     vol = torch.zeros(n ** 3, dtype=torch.int32, device="cuda")
@@ -27,18 +34,19 @@ def main():
     smap = torch.zeros(capi.surface_map_bytes(plain) // 4, dtype=torch.int32, device="cuda")
     desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT, surface_map=smap.data_ptr())
     d_dists = torch.empty((synth.ROWS, synth.COLS), dtype=torch.int16, device="cuda")
-    for f in range(0, 300, 15):
+    for f in ([] if args.empty else range(0, 300, 15)):
         depth, R, t = synth.scene_s2(f)
         d_depth = torch.from_numpy(depth.view(np.int16)).cuda()
         ctx.compute_dists(d_depth.data_ptr(), synth.COLS * 2, d_dists.data_ptr(), synth.COLS * 2, synth.ROWS, synth.COLS,
                           synth.INTR)
         ctx.integrate(desc, d_dists.data_ptr(), synth.COLS * 2, synth.ROWS, synth.COLS, R.reshape(-1), t, synth.INTR)
     torch.cuda.synchronize()
-    marked = int(sum(bin(int(w) & 0xffffffff).count("1") for w in smap.cpu().numpy()))
+    nw = ((n + 15) // 16) ** 3 // 32  # brick words; the cell words follow
+    marked = int(sum(bin(int(w) & 0xffffffff).count("1") for w in smap.cpu().numpy()[:nw]))
     kept = smap.clone()
     ctx.surface_map_rebuild(desc)
     torch.cuda.synchronize()
-    exact = int(sum(bin(int(w) & 0xffffffff).count("1") for w in smap.cpu().numpy()))
+    exact = int(sum(bin(int(w) & 0xffffffff).count("1") for w in smap.cpu().numpy()[:nw]))
     missing = int((smap & ~kept).ne(0).sum().item())
     print("surface map: %d bricks marked by integrate, %d hold a negative voxel, %d of those unmarked (must be 0), %d bricks"
           % (marked, exact, missing, (n // 16) ** 3), flush=True)

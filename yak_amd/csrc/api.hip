@@ -75,10 +75,10 @@ static int check_volume(const yakhip_volume* v)
   return 0;
 }
 
-// 32-bit words of a slab's surface map (yakhip.h): one bit per 16^3 brick of its layers
+// 32-bit words of a slab's surface map (yakhip.h): one bit per 16^3 brick of its layers, then one per 64^3 cell
 static size_t surface_map_words(const yakhip_volume* v)
 {
-  return surface_brick_words(v->dims[0], v->dims[1], v->z1 - v->z0);
+  return surface_brick_words(v->dims[0], v->dims[1], v->z1 - v->z0) + surface_cell_words(v->dims[0], v->dims[1], v->z1 - v->z0);
 }
 }  // namespace yakhip
 
@@ -134,6 +134,7 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->brick_test = 1;
   ctx->chunk_order = -1;
   ctx->surface_skip = 1;
+  ctx->raycast_bands = -1;
   ctx->chunk_min = 0;
   ctx->chunk_ramp = 0;
   ctx->checkpoint = 1;
@@ -291,6 +292,11 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
   if (strcmp(key, "icp_poll") == 0)
   {
     ctx->icp_poll = value != 0;
+    return 0;
+  }
+  if (strcmp(key, "raycast_bands") == 0)
+  {
+    ctx->raycast_bands = (int)value;  // -1 automatic, 0 image order, 1 XCD bands, >= 2 scattered with about this stride
     return 0;
   }
   if (strcmp(key, "surface_skip") == 0)
@@ -743,6 +749,8 @@ static int fill_integrate_params(IntegrateParams& p, const yakhip_volume* vol, c
   p.bricks = (uint32_t*)vol->surface_map;
   p.bricks_x = (vol->dims[0] + 15) >> 4;
   p.bricks_y = (vol->dims[1] + 15) >> 4;
+  p.bricks_z = (vol->z1 - vol->z0 + 15) >> 4;
+  p.bricks_words = (uint32_t)surface_brick_words(vol->dims[0], vol->dims[1], vol->z1 - vol->z0);
   p.dists = (const uint8_t*)dists_dev;
   p.thr = nullptr;  // thr, coarse, cw/ch and the grp_* constants are filled by the launcher
   p.coarse = nullptr;
@@ -900,6 +908,22 @@ static int raycast_common(yakhip_ctx* ctx, const yakhip_volume* vol, const float
   p.skip_x = (vol->dims[0] + 15) >> 4, p.skip_y = (vol->dims[1] + 15) >> 4;
   const size_t words = surface_brick_words(vol->dims[0], vol->dims[1], vol->z1 - vol->z0);
   p.skip_words = words <= 0x3fffffffull ? (int)words : 0x3fffffff;
+  p.cell_x = (p.skip_x + 3) >> 2, p.cell_y = (p.skip_y + 3) >> 2, p.cell_z = (((vol->z1 - vol->z0 + 15) >> 4) + 3) >> 2;
+  p.cell_words = (int)surface_cell_words(vol->dims[0], vol->dims[1], vol->z1 - vol->z0);
+  // Crossing free space in one go (raycast.hip) rests on the marched samples -- positions and times built by
+  // repeated rounded additions -- staying close to the straight line: every addition is off by at most half an
+  // ulp of the largest value it can reach (a coordinate inside the volume; the time from the camera to the far
+  // corner), over at most diagonal / step additions.  Positions must stay within an eighth of a voxel, times
+  // within a quarter of a step (the jump keeps two steps and 16 voxels in hand).
+  {
+    const float diag = sqrtf(p.bx * p.bx + p.by * p.by + p.bz * p.bz);
+    const float vmin = fminf(fminf(p.vsx, p.vsy), p.vsz), vmax = fmaxf(fmaxf(p.vsx, p.vsy), p.vsz);
+    const float pos_reach = fmaxf(fmaxf(p.bx, p.by), p.bz) + 2.f * vmax;
+    const float time_reach = sqrtf(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]) + diag;
+    const float steps = diag / p.time_step + 8.f;
+    p.cell_jump = steps < 1e6f && time_reach < 1e6f && steps * 0x1p-23f * pos_reach < 0.125f * vmin &&
+                  steps * 0x1p-23f * time_reach < 0.25f * p.time_step;
+  }
   p.vol_bytes = (unsigned long long)vol->dims[0] * (unsigned long long)vol->dims[1] * (unsigned long long)(vol->z1 - vol->z0) * 4ull;
   return launch_raycast(ctx, p);
 }

@@ -634,6 +634,8 @@ __device__ __forceinline__ void update(const IntegrateParams& p, const Pos<VX>& 
 // are negative only behind the surface inside the truncation band: the walk collects the lanes that took one
 // (`band`, a wave mask in SGPRs, updated on the band path of settle() only) and sets their brick's bit when it
 // leaves the brick's layers.
+// A second level (one bit per cell of 4 x 4 x 4 bricks, set with the first marking of a brick in or next to the cell)
+// lets the ray cast cross the free space in front of the first marked cell in one go.
 // Bits are only ever set here; yakhip_clear_volume clears them, yakhip_surface_map_rebuild recomputes them.
 constexpr int kBrickShift = 4;  // YAKHIP_SURFACE_BRICK = 16
 
@@ -643,8 +645,8 @@ __device__ __forceinline__ void mark_bricks(const IntegrateParams& p, mask_t ban
     return;
   if (lanes(band))
   {
-    const uint32_t b = (uint32_t)(x0 >> kBrickShift) +
-                       (uint32_t)p.bricks_x * ((uint32_t)(y >> kBrickShift) + (uint32_t)p.bricks_y * (uint32_t)(z_rel >> kBrickShift));
+    const int bx = x0 >> kBrickShift, by = y >> kBrickShift, bz = z_rel >> kBrickShift;
+    const uint32_t b = (uint32_t)bx + (uint32_t)p.bricks_x * ((uint32_t)by + (uint32_t)p.bricks_y * (uint32_t)bz);
     uint32_t* word = p.bricks + (b >> 5);
     const uint32_t bit = 1u << (b & 31u);
     if (!(__builtin_nontemporal_load(word) & bit))  // (a stale line only costs a redundant atomic)
@@ -652,13 +654,27 @@ __device__ __forceinline__ void mark_bricks(const IntegrateParams& p, mask_t ban
   }
 }
 
+// The second level for the lanes that marked a brick during a walk over the layers [zs_rel, ze_rel): after the walk
+// (the loop's registers are dead by then), for every brick layer the walk touched -- a superset of the bricks
+// actually marked, which is all a "may hold" bit has to be.
+__device__ __forceinline__ void mark_cells(const IntegrateParams& p, mask_t marked, int x0, int y, int zs_rel, int ze_rel)
+{
+  if (marked == 0)  // wave-uniform
+    return;
+  if (lanes(marked))
+    for (int bz = zs_rel >> kBrickShift; bz <= (ze_rel - 1) >> kBrickShift; ++bz)
+      surface_mark_cells(p.bricks, p.bricks_words, p.bricks_x, p.bricks_y, p.bricks_z, x0 >> kBrickShift, y >> kBrickShift, bz);
+}
+
 // after the layers z, z + 1 (z - z0 even or odd) have been settled: flush `band` if the next layer starts another brick
 // or the walk ends
-__device__ __forceinline__ void flush_bricks(const IntegrateParams& p, mask_t& band, int x0, int y, int z, int step, int end)
+__device__ __forceinline__ void flush_bricks(const IntegrateParams& p, mask_t& band, mask_t& marked, int x0, int y, int z,
+                                             int step, int end)
 {
   const int r = z - p.z0;
   if (((r + step) >> kBrickShift) != (r >> kBrickShift) || z + step >= end)
   {
+    marked |= band;
     mark_bricks(p, band, x0, y, r);
     if (step > 1 && ((r + step - 1) >> kBrickShift) != (r >> kBrickShift) && z + step - 1 < end)
       mark_bricks(p, band, x0, y, r + step - 1);  // (an odd chunk start: the pair of layers straddles two bricks)
@@ -1006,6 +1022,7 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
   __builtin_amdgcn_sched_barrier(0);
   uint32_t soff = 0;
   mask_t band = 0;  // lanes that folded a negative measurement into a voxel since the last flush (surface map)
+  mask_t marked = 0;  // ... at any time during this walk
   for (int z = ws; z < we; z += 2, soff += 2u * layer_bytes)
   {
     // layer z lives in set A, layer z+1 in set B.  Stage 1 runs one layer ahead and is not guarded at
@@ -1018,8 +1035,10 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
     update<VX, NT>(p, B, PB, bufB, validB, rs, voff, soff + layer_bytes, layer_bytes, z + 1 < we, z + 3 < we,
                    max_w_hi, band);
     if (p.bricks)
-      flush_bricks(p, band, x0, y, z, 2, we);
+      flush_bricks(p, band, marked, x0, y, z, 2, we);
   }
+  if (p.bricks)
+    mark_cells(p, marked, x0, y, ws - p.z0, we - p.z0);
 }
 
 template <int VX>
@@ -1492,7 +1511,7 @@ __global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchPara
                                                       (uint32_t)(ze - zs) * layer_bytes, 0x00020000);
   const uint32_t voff = elem * 4u;
 
-  mask_t band = 0;      // (surface map, see the single-frame kernel)
+  mask_t band = 0, marked = 0;  // (surface map, see the single-frame kernel)
   mask_t have = ~0ull;  // lanes whose `cur` holds this layer's voxels
   vec_t cur = buf_load<VX, NT>(rs, voff, 0u);
   uint32_t soff = 0;
@@ -1551,8 +1570,10 @@ __global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchPara
     have = z + 1 < ze ? any : 0;
     cur = buf_load<VX, NT>(rs, lanes(have) ? voff : kNoAccess, z + 1 < ze ? soff + layer_bytes : 0u);
     if (p.bricks)
-      flush_bricks(p, band, x0, y, z, 1, ze);
+      flush_bricks(p, band, marked, x0, y, z, 1, ze);
   }
+  if (p.bricks)
+    mark_cells(p, marked, x0, y, zs - p.z0, ze - p.z0);
 }
 
 template <int K>

@@ -30,7 +30,10 @@ namespace yakhip
 {
 namespace
 {
-constexpr int kUnroll = 4;
+constexpr int kUnrollPlain = 4;
+#ifndef YAK_RAYCAST_UNROLL_SKIP
+#define YAK_RAYCAST_UNROLL_SKIP 8
+#endif
 constexpr int kMaxSkipWords = 8192;  // 32 KiB of LDS: 2^18 bricks, e.g. 1024^3 voxels or a 2048 x 2048 x 256 slab
 
 template <bool IDX32>
@@ -179,13 +182,15 @@ __global__ __launch_bounds__(256) void raycast_kernel(const RaycastParams p, int
   // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; give each XCD a
   // contiguous run of tiles (a band of the image) so that its L2 sees one part of the volume.
   const int bid = (int)blockIdx.x;
-  const int tile = (bid & 7) * per_xcd + (bid >> 3);
+  // per_xcd < 0: tiles in a scattered order (stride -per_xcd, coprime to the tile count): with the surface map
+  // the cost of a tile is its hits, which come in patches of the image
+  const int tile = per_xcd > 0 ? (bid & 7) * per_xcd + (bid >> 3) : (per_xcd < 0 ? (int)(((long long)bid * -per_xcd) % n_tiles) : bid);
   if (tile >= n_tiles)
     return;
   extern __shared__ uint32_t map_lds[];
   if constexpr (SKIP)
   {
-    for (int i = (int)threadIdx.x; i < p.skip_words; i += 256)
+    for (int i = (int)threadIdx.x; i < p.skip_words + p.cell_words; i += 256)
       map_lds[i] = p.skip[i];
     __syncthreads();
   }
@@ -239,8 +244,91 @@ __global__ __launch_bounds__(256) void raycast_kernel(const RaycastParams p, int
       tsdf_next = fetch_tsdf_skip<SLAB>(p, rs, map_lds, nx, ny, nz, own_next, scratch, skip_next);
     else
       tsdf_next = fetch_tsdf<IDX32, SLAB>(p, nx, ny, nz, own_next, scratch);
+    if constexpr (SKIP)
+    {
+      // Free space in one go.  Walk the cells of 64^3 voxels the straight ray passes through, from its entry into
+      // the volume, until one is marked (a marked brick in it or within 16 voxels of it) or the ray leaves: up to
+      // there every sample lies in an unmarked brick, so every pair is a pair of values >= 0 and cannot end the
+      // march (tsdf_volume.cu:326-331).  Only the march's own arithmetic is replayed for those pairs -- the same
+      // rounded additions of position and time, the same tcurr < tmax test per step -- two steps short of the
+      // marked cell; the marched samples stay within an eighth of a voxel of the straight line (cell_jump,
+      // api.hip), far inside the 16 voxels the cell bits keep clear.  Slab mode: layers that are not held count as
+      // free (their samples read 0 and their pairs are another slab's).
+      if (p.cell_jump && (skip_next || (SLAB && !scratch)))
+      {
+        // voxel-index coordinates shifted by one half: floor(u / 64) is the cell of the voxel that rint() picks
+        const float zb = SLAB ? (float)p.z_base : 0.f;
+        const float ux = nx * p.ivx + 0.5f, uy = ny * p.ivy + 0.5f, uz = nz * p.ivz + 0.5f - zb;
+        const float gx = dx * p.ivx, gy = dy * p.ivy, gz = dz * p.ivz;  // d(u) / dt
+        int cxi = clampi((int)__builtin_floorf(ux * (1.f / 64.f)), p.cell_x - 1);
+        int cyi = clampi((int)__builtin_floorf(uy * (1.f / 64.f)), p.cell_y - 1);
+        int czi = (int)__builtin_floorf(uz * (1.f / 64.f));
+        if constexpr (!SLAB)
+          czi = clampi(czi, p.cell_z - 1);
+        const float igx = __builtin_amdgcn_rcpf(gx), igy = __builtin_amdgcn_rcpf(gy), igz = __builtin_amdgcn_rcpf(gz);
+        const float big = 3.0e38f;
+        // time at which the ray crosses into the next cell along each axis, and the time between crossings
+        float tx = gx > 0.f ? tmin + ((float)((cxi + 1) << 6) - ux) * igx : (gx < 0.f ? tmin + ((float)(cxi << 6) - ux) * igx : big);
+        float ty = gy > 0.f ? tmin + ((float)((cyi + 1) << 6) - uy) * igy : (gy < 0.f ? tmin + ((float)(cyi << 6) - uy) * igy : big);
+        float tz = gz > 0.f ? tmin + ((float)((czi + 1) * 64) - uz) * igz : (gz < 0.f ? tmin + ((float)(czi * 64) - uz) * igz : big);
+        const float ex = 64.f * __builtin_fabsf(igx), ey = 64.f * __builtin_fabsf(igy), ez = 64.f * __builtin_fabsf(igz);
+        const int stx = gx > 0.f ? 1 : -1, sty = gy > 0.f ? 1 : -1, stz = gz > 0.f ? 1 : -1;
+        float t_free = tmin;
+        for (int guard = 0; guard < 4096; ++guard)
+        {
+          if ((unsigned)cxi >= (unsigned)p.cell_x || (unsigned)cyi >= (unsigned)p.cell_y)
+            break;  // the ray has left the volume
+          // (slab mode: the cell layer next to the held ones answers for its held neighbour -- a sample an eighth of
+          // a voxel off the straight line may already lie in a held layer; cells farther out are free)
+          const int czl = SLAB && czi == -1 ? 0 : (SLAB && czi == p.cell_z ? p.cell_z - 1 : czi);
+          const bool held_z = (unsigned)czl < (unsigned)p.cell_z;
+          if (!SLAB && !held_z)
+            break;
+          if (held_z)
+          {
+            const uint32_t c = (uint32_t)cxi + (uint32_t)p.cell_x * ((uint32_t)cyi + (uint32_t)p.cell_y * (uint32_t)czl);
+            if ((map_lds[p.skip_words + (c >> 5)] >> (c & 31u)) & 1u)
+              break;
+          }
+          // into the next cell
+          if (tx <= ty && tx <= tz)
+            t_free = tx, tx += ex, cxi += stx;
+          else if (ty <= tz)
+            t_free = ty, ty += ey, cyi += sty;
+          else
+            t_free = tz, tz += ez, czi += stz;
+          if (!(t_free < tmax))
+            break;
+        }
+        const float room = (fminf(t_free, tmax) - tmin) / ts - 2.f;
+        const int steps = room > 0.f ? (int)fminf(room, 1.0e6f) : 0;
+        f32x2 pxy = { nx, ny }, pzt = { nz, tcurr };
+        const f32x2 sxy = { sx, sy }, szt = { sz, ts };
+        int done = 0;
+        for (; done < steps; ++done)
+        {
+          if (!(pzt.y < tmax))
+          {
+            state = 2;
+            break;
+          }
+          pxy += sxy;
+          pzt += szt;
+        }
+        nx = pxy.x, ny = pxy.y, nz = pzt.x, tcurr = pzt.y;
+        pair += done;
+        if (done > 0)
+          skip_next = true;  // the sample now stood on reads as +0: unmarked brick, or a layer that is not held
+        if constexpr (SLAB)
+        {
+          const int zn = clampi((int)__builtin_rintf(nz * p.ivz), p.Z - 1);
+          own_next = zn >= p.z_own0 && zn < p.z_own1;
+        }
+      }
+    }
     while (state == 0)
     {
+      constexpr int kUnroll = SKIP ? YAK_RAYCAST_UNROLL_SKIP : kUnrollPlain;
       float qx[kUnroll], qy[kUnroll], qz[kUnroll], f[kUnroll];
       bool own[kUnroll], held[kUnroll], skip[kUnroll];
       float ax = nx, ay = ny, az = nz;
@@ -444,7 +532,7 @@ __global__ __launch_bounds__(256) void extract_normals_kernel(const RaycastParam
 // the 16 voxels of row (y = t & 15, z = t >> 4) of the brick; a voxel is negative if its half has the sign bit
 // and a non-zero magnitude.
 __global__ __launch_bounds__(256) void surface_scan_kernel(const uint32_t* vol, int X, int Y, int layers, int bricks_x,
-                                                           int bricks_y, uint32_t* map)
+                                                           int bricks_y, int bricks_z, uint32_t* map, uint32_t brick_words)
 {
   const uint32_t b = blockIdx.x;
   const int bx = (int)(b % (uint32_t)bricks_x), by = (int)((b / (uint32_t)bricks_x) % (uint32_t)bricks_y),
@@ -468,7 +556,10 @@ __global__ __launch_bounds__(256) void surface_scan_kernel(const uint32_t* vol, 
     any = 1;
   __syncthreads();
   if (threadIdx.x == 0 && any)
+  {
     atomicOr(map + (b >> 5), 1u << (b & 31u));
+    surface_mark_cells(map, brick_words, bricks_x, bricks_y, bricks_z, bx, by, bz);
+  }
 }
 }  // namespace
 
@@ -478,8 +569,10 @@ int launch_surface_scan(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int 
   const unsigned long long bricks = (unsigned long long)bx * by * bz;
   if (bricks > 0x7fffffffull)
     return fail(YAKHIP_ERANGE, "surface_map_rebuild: too many bricks");
-  YAKHIP_TRY(hipMemsetAsync(map, 0, surface_brick_words(X, Y, layers) * 4u, ctx->stream));
-  hipLaunchKernelGGL(surface_scan_kernel, dim3((unsigned)bricks), dim3(256), 0, ctx->stream, vol, X, Y, layers, bx, by, map);
+  const size_t brick_words = surface_brick_words(X, Y, layers);
+  YAKHIP_TRY(hipMemsetAsync(map, 0, (brick_words + surface_cell_words(X, Y, layers)) * 4u, ctx->stream));
+  hipLaunchKernelGGL(surface_scan_kernel, dim3((unsigned)bricks), dim3(256), 0, ctx->stream, vol, X, Y, layers, bx, by, bz, map,
+                     (uint32_t)brick_words);
   return check(hipGetLastError(), "surface_scan_kernel launch");
 }
 
@@ -531,16 +624,30 @@ int launch_raycast(yakhip_ctx* ctx, const RaycastParams& p)
   if (rc != 0)
     return rc;
   // the surface map travels in LDS: volumes whose map is too large for that are marched without it
-  const bool skip = p.skip != nullptr && p.skip_words <= kMaxSkipWords && p.vol_bytes < 0x80000000ull && ctx->surface_skip;
-  const size_t lds = skip ? (size_t)p.skip_words * 4u : 0;
+  const bool skip = p.skip != nullptr && p.skip_words + p.cell_words <= kMaxSkipWords && p.vol_bytes < 0x80000000ull &&
+                    ctx->surface_skip;
+  const size_t lds = skip ? (size_t)(p.skip_words + p.cell_words) * 4u : 0;
 #define YAK_RAYCAST_LAUNCH(I, S)                                                                                    \
   do                                                                                                               \
   {                                                                                                                \
     if (skip)                                                                                                      \
-      hipLaunchKernelGGL((raycast_kernel<I, S, true>), grid, dim3(256), lds, ctx->stream, p, tiles_x, n_tiles, per_xcd);  \
+      hipLaunchKernelGGL((raycast_kernel<I, S, true>), grid, dim3(256), lds, ctx->stream, p, tiles_x, n_tiles, per_xcd_arg);  \
     else                                                                                                           \
-      hipLaunchKernelGGL((raycast_kernel<I, S, false>), grid, dim3(256), lds, ctx->stream, p, tiles_x, n_tiles, per_xcd); \
+      hipLaunchKernelGGL((raycast_kernel<I, S, false>), grid, dim3(256), lds, ctx->stream, p, tiles_x, n_tiles, per_xcd_arg); \
   } while (0)
+  // XCD bands pay while the march fetches (each L2 sees one part of the volume: 0.057 against 0.070 ms along z);
+  // with the surface map a tile costs its hits, which come in patches of the image, and plain image order spreads
+  // them best (0.056-0.066 ms against 0.064-0.089 in bands, 0.060-0.072 scattered)
+  const int bands = ctx->raycast_bands >= 0 ? ctx->raycast_bands : (skip ? 0 : 1);
+  int per_xcd_arg = bands == 1 ? per_xcd : 0;
+  if (bands >= 2)
+  {
+    int stride = bands;
+    auto gcd = [](int a, int b) { while (b) { const int r = a % b; a = b; b = r; } return a; };
+    while (gcd(stride, n_tiles) != 1)
+      ++stride;
+    per_xcd_arg = -stride;
+  }
   if (slab && idx32)
     YAK_RAYCAST_LAUNCH(true, true);
   else if (slab)

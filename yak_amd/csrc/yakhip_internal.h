@@ -22,6 +22,7 @@ struct yakhip_ctx
   int chunk_order;     // -1 automatic; 0 ascending, 1 shallow / deep in turn, 3 deepest first (tuning)
   int chunk_min;       // 0 automatic; shortest chunk of a graded table, layers (tuning)
   int chunk_ramp;      // 0 automatic (6); a chunk starting at layer zs is about zs / ramp layers long; -1: all chunks alike (tuning)
+  int raycast_bands;   // ray-cast tiles: -1 automatic, 1 each XCD a contiguous band of the image, 0 image order, >= 2 scattered
   int surface_skip;    // the ray cast consults a volume's surface map (default) / ignores it
   int brick_test;      // classify whole bricks (dead / front / mixed) before walking them (default) / off
   int checkpoint;      // deep slabs start from closed-form column positions (default) / replay from layer 0
@@ -84,8 +85,9 @@ struct IntegrateParams
   const float* cellmin;  // brick test: min of A2 / max of the B2 word over each 16 x 16 pixel cell, ccw x cch cells
   const float* cellmax;
   int ccw, cch;
-  uint32_t* bricks;      // nullptr, or the slab's surface map: one bit per 16^3 brick, bricks_x x bricks_y x layers / 16
-  int bricks_x, bricks_y;
+  uint32_t* bricks;      // nullptr, or the slab's surface map: one bit per 16^3 brick, bricks_x x bricks_y x bricks_z,
+  int bricks_x, bricks_y, bricks_z;  // then (bricks_words 32-bit words on) one bit per cell of 4 x 4 x 4 bricks
+  uint32_t bricks_words;
   uint32_t* brick_stats; // nullptr, or counters {mixed, dead, front} of classified wave bricks ("brick_stats" option)
   int brick_enable;      // classify each workgroup's brick (x-y tile times z-chunk) before walking it
   float brick_eps;       // bound on |replayed fp32 position - ideal position| per camera coordinate (metres)
@@ -119,6 +121,28 @@ struct ChunkTable
   uint16_t layers[kMaxChunks];
 };
 
+// Surface map, second level: after brick (bx, by, bz) of a bricks_x x bricks_y x bricks_z grid has been marked, mark
+// the cells (4 x 4 x 4 bricks, bits from word `words` on) that hold it or are touched by it from next door.
+__device__ __forceinline__ void surface_mark_cells(uint32_t* map, uint32_t words, int bricks_x, int bricks_y, int bricks_z,
+                                                   int bx, int by, int bz)
+{
+  const int ncx = (bricks_x + 3) >> 2, ncy = (bricks_y + 3) >> 2, ncz = (bricks_z + 3) >> 2;
+  const int cx = bx >> 2, cy = by >> 2, cz = bz >> 2;
+  const int x0 = (bx & 3) == 0 && cx > 0 ? cx - 1 : cx, x1 = (bx & 3) == 3 && cx + 1 < ncx ? cx + 1 : cx;
+  const int y0 = (by & 3) == 0 && cy > 0 ? cy - 1 : cy, y1 = (by & 3) == 3 && cy + 1 < ncy ? cy + 1 : cy;
+  const int z0 = (bz & 3) == 0 && cz > 0 ? cz - 1 : cz, z1 = (bz & 3) == 3 && cz + 1 < ncz ? cz + 1 : cz;
+  for (int z = z0; z <= z1; ++z)
+    for (int y = y0; y <= y1; ++y)
+      for (int x = x0; x <= x1; ++x)
+      {
+        const uint32_t c = (uint32_t)x + (uint32_t)ncx * ((uint32_t)y + (uint32_t)ncy * (uint32_t)z);
+        uint32_t* word = map + words + (c >> 5);
+        const uint32_t bit = 1u << (c & 31u);
+        if (!(__builtin_nontemporal_load(word) & bit))  // (the steady state: set long ago; a stale line costs one atomic)
+          atomicOr(word, bit);
+      }
+}
+
 // Ray casting (raycast.hip).  Everything wave-uniform travels in the kernarg segment.
 struct RaycastParams
 {
@@ -144,7 +168,10 @@ struct RaycastParams
   // surface map of the held layers (yakhip_volume.surface_map) or nullptr: one bit per 16^3 brick, skip_x x skip_y
   // bricks per brick layer, skip_words 32-bit words in all
   const uint32_t* skip;
-  int skip_x, skip_y, skip_words;  // bricks per row / column, 32-bit words
+  int skip_x, skip_y, skip_words;  // bricks per row / column, 32-bit words of brick bits
+  int cell_x, cell_y, cell_z;      // cells (4 x 4 x 4 bricks) per row / column / in z; their bits follow the brick bits
+  int cell_words;
+  int cell_jump;                   // 1: the march may cross the free space in front of the first marked cell in one go
   unsigned long long vol_bytes;    // bytes of the held layers
 };
 
@@ -152,6 +179,12 @@ struct RaycastParams
 inline size_t surface_brick_words(int X, int Y, int layers)
 {
   return ((size_t)((X + 15) >> 4) * (size_t)((Y + 15) >> 4) * (size_t)((layers + 15) >> 4) + 31u) / 32u;
+}
+// ... followed by one bit per cell of 64^3 voxels (4 x 4 x 4 bricks): set when a marked brick lies in the cell or
+// touches it from a neighbouring cell, i.e. clear = no marked brick within 16 voxels of the cell
+inline size_t surface_cell_words(int X, int Y, int layers)
+{
+  return ((size_t)((X + 63) >> 6) * (size_t)((Y + 63) >> 6) * (size_t)((layers + 63) >> 6) + 31u) / 32u;
 }
 
 // use_static: thresholds / checkpoints go to the file-scope array instead of context-owned buffers, and the
