@@ -66,7 +66,9 @@ typedef struct yakhip_volume
 /* The surface map of a slab (no counterpart in the reference; optional): one bit per brick of
  * YAKHIP_SURFACE_BRICK^3 voxels of the slab's layers [z0, z1) -- bit (bx + BX * (by + BY * bz)) of an array of
  * 32-bit words, BX = ceil(X / 16), BY = ceil(Y / 16), bz counted from layer z0 -- set when the brick MAY hold a voxel
- * with a negative tsdf.  The ray cast can only stop between two samples of which one is negative
+ * with a negative tsdf; then, from the next word on, one bit per cell of 4 x 4 x 4 bricks in the same order, set
+ * when a marked brick lies in the cell or touches it from a neighbouring cell (the ray cast crosses the free space in
+ * front of the first marked cell without looking at its samples).  The ray cast can only stop between two samples of which one is negative
  * (yak/src/cuda/tsdf_volume.cu:326-331), so it does not fetch the samples that fall into bricks whose bit is
  * clear; the images are the same bit for bit, with or without a map.
  *   yakhip_integrate / _static / _batch   set the bits of the bricks in which a negative measurement was folded
