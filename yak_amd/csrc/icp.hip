@@ -162,7 +162,9 @@ __device__ __forceinline__ double fast_rsqrt(double x)
 // (solve6.hpp) redoes the estimate.
 __device__ __forceinline__ void solve_update(const float* sums, IcpState& st)
 {
-#pragma clang fp contract(fast)  // double precision, nothing here is compared bit for bit: fused multiply-adds halve the chain
+  // Double precision with the fused multiply-adds written out (they halve the dependent chain): this translation
+  // unit is compiled without contraction, so the arithmetic is the same in whichever kernel the function is
+  // inlined -- the chain of launches and the one-launch schedule give the same bits.
   // StreamHelper::get, projective_icp.cpp:42-61.  Every loop below has constant bounds and is unrolled,
   // so the 6 x 6 system lives in registers (double precision).
   double A[6][6], b[6];
@@ -194,7 +196,7 @@ __device__ __forceinline__ void solve_update(const float* sums, IcpState& st)
     double d = A[j][j];
 #pragma unroll
     for (int k = 0; k < j; ++k)
-      d -= A[j][k] * A[j][k];
+      d = __builtin_fma(-A[j][k], A[j][k], d);
     spd = spd && d > 0.0;
     const double dd = spd ? d : 1.0;
     const double rs = fast_rsqrt(dd);
@@ -209,7 +211,7 @@ __device__ __forceinline__ void solve_update(const float* sums, IcpState& st)
       double v = A[i][j];
 #pragma unroll
       for (int k = 0; k < j; ++k)
-        v -= A[i][k] * A[j][k];
+        v = __builtin_fma(-A[i][k], A[j][k], v);
       A[i][j] = v * rs;
     }
   }
@@ -226,16 +228,16 @@ __device__ __forceinline__ void solve_update(const float* sums, IcpState& st)
     for (int j = 0; j < 6; ++j)
     {
       M[j][j] = inv[j];
-      frob += inv[j] * inv[j];
+      frob = __builtin_fma(inv[j], inv[j], frob);
 #pragma unroll
       for (int i = j + 1; i < 6; ++i)
       {
         double v = 0.0;
 #pragma unroll
         for (int k = j; k < i; ++k)
-          v -= A[i][k] * M[k][j];
+          v = __builtin_fma(-A[i][k], M[k][j], v);
         M[i][j] = v * inv[i];
-        frob += M[i][j] * M[i][j];
+        frob = __builtin_fma(M[i][j], M[i][j], frob);
       }
     }
     certified = frob * cutoff < 1.0;
@@ -252,7 +254,7 @@ __device__ __forceinline__ void solve_update(const float* sums, IcpState& st)
     double v = b[i];
 #pragma unroll
     for (int k = 0; k < i; ++k)
-      v -= A[i][k] * y[k];
+      v = __builtin_fma(-A[i][k], y[k], v);
     y[i] = v * inv[i];
   }
 #pragma unroll
@@ -261,7 +263,7 @@ __device__ __forceinline__ void solve_update(const float* sums, IcpState& st)
     double v = y[i];
 #pragma unroll
     for (int k = i + 1; k < 6; ++k)
-      v -= A[k][i] * r[k];
+      v = __builtin_fma(-A[k][i], r[k], v);
     r[i] = v * inv[i];
   }
 
@@ -270,16 +272,17 @@ __device__ __forceinline__ void solve_update(const float* sums, IcpState& st)
   const float rv[3] = { (float)r[0], (float)r[1], (float)r[2] };
   const float tinc[3] = { (float)r[3], (float)r[4], (float)r[5] };
   float Ri[9] = { 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f };
-  const double th2 = (double)rv[0] * rv[0] + (double)rv[1] * rv[1] + (double)rv[2] * rv[2];
+  const double th2 = __builtin_fma((double)rv[2], (double)rv[2], __builtin_fma((double)rv[1], (double)rv[1], (double)rv[0] * rv[0]));
   if (th2 > 2.220446049250313e-16 * 2.220446049250313e-16)  // theta > DBL_EPSILON
   {
     const double inv_th = fast_rsqrt(th2), th = th2 * inv_th;
     double s, c;
     sincos(th, &s, &c);
     const double kx = rv[0] * inv_th, ky = rv[1] * inv_th, kz = rv[2] * inv_th, v = 1.0 - c;
-    Ri[0] = (float)(c + kx * kx * v), Ri[1] = (float)(kx * ky * v - kz * s), Ri[2] = (float)(kx * kz * v + ky * s);
-    Ri[3] = (float)(ky * kx * v + kz * s), Ri[4] = (float)(c + ky * ky * v), Ri[5] = (float)(ky * kz * v - kx * s);
-    Ri[6] = (float)(kz * kx * v - ky * s), Ri[7] = (float)(kz * ky * v + kx * s), Ri[8] = (float)(c + kz * kz * v);
+    const double xx = kx * kx * v, yy = ky * ky * v, zz = kz * kz * v, xy = kx * ky * v, xz = kx * kz * v, yz = ky * kz * v;
+    Ri[0] = (float)(c + xx), Ri[1] = (float)__builtin_fma(-kz, s, xy), Ri[2] = (float)__builtin_fma(ky, s, xz);
+    Ri[3] = (float)__builtin_fma(kz, s, xy), Ri[4] = (float)(c + yy), Ri[5] = (float)__builtin_fma(-kx, s, yz);
+    Ri[6] = (float)__builtin_fma(-ky, s, xz), Ri[7] = (float)__builtin_fma(kx, s, yz), Ri[8] = (float)(c + zz);
   }
   float Rn[9], tn[3];
 #pragma unroll
@@ -311,6 +314,146 @@ __device__ __forceinline__ void load_state(const IcpState* src, IcpState& st)  /
   st.iterations = src->iterations;
 }
 
+// The pixels of one lane of a 256-lane block: block `block` covers the 1024 consecutive pixels from block * 1024.
+struct CurrentMaps
+{
+  bool live[kPixelsPerLane];
+  float4 s0[kPixelsPerLane], nc[kPixelsPerLane];
+};
+
+// The loads of the current maps do not depend on the pose: they are issued before the pose is worked out and
+// fly meanwhile.
+__device__ __forceinline__ void load_current(const IcpParams& p, int block, int tid, CurrentMaps& c)
+{
+  const int n_pixels = p.rows * p.cols;
+  const int base = block * (256 * kPixelsPerLane) + tid;
+#pragma unroll
+  for (int i = 0; i < kPixelsPerLane; ++i)
+  {
+    const int pix = base + i * 256;
+    c.live[i] = pix < n_pixels;
+    const int pc = c.live[i] ? pix : (n_pixels > 0 ? n_pixels - 1 : 0);  // a dead lane re-reads the band's last pixel (an empty
+                                                                         // band of the sharded schedule: pixel (row0, 0), a valid row)
+    const int yr = pc / p.cols, x = pc - yr * p.cols, y = yr + p.row0;
+    c.s0[i] = f4_at(p.vcurr, p.vcurr_pitch, y, x);
+    c.nc[i] = f4_at(p.ncurr, p.ncurr_pitch, y, x);
+  }
+}
+
+// The four pixels of a lane are independent until their sums meet, and the kernel is latency-bound (one
+// or two waves per SIMD, each pixel a chain load -> project -> gather): all four current-map loads go
+// out together (load_current), then all four gathers, then the arithmetic -- pixel by pixel in the old order, so
+// the sums are bit for bit what the one-pixel-at-a-time loop gave.
+__device__ __forceinline__ void accumulate_pixels(const IcpParams& p, const float (&R)[9], const float (&t)[3],
+                                                  const CurrentMaps& c, float (&acc)[kValues])
+{
+  float4 d[kPixelsPerLane], nd[kPixelsPerLane];
+  int code[kPixelsPerLane];
+  float sx[kPixelsPerLane], sy[kPixelsPerLane], sz[kPixelsPerLane];
+#pragma unroll
+  for (int i = 0; i < kPixelsPerLane; ++i)
+  {
+    // find_coresp, proj_icp.cu:74-102, up to the fetch of the destination point
+    code[i] = 0;
+    sx[i] = sy[i] = sz[i] = 0.f;
+    int px = 0, py = 0;
+    if (c.s0[i].x != c.s0[i].x)
+      code[i] = 40;
+    else
+    {
+      sx[i] = dot3(R[0], R[1], R[2], c.s0[i].x, c.s0[i].y, c.s0[i].z) + t[0];
+      sy[i] = dot3(R[3], R[4], R[5], c.s0[i].x, c.s0[i].y, c.s0[i].z) + t[1];
+      sz[i] = dot3(R[6], R[7], R[8], c.s0[i].x, c.s0[i].y, c.s0[i].z) + t[2];
+      if (sz[i] <= 0.f)
+        code[i] = 80;
+      else
+      {
+        const float coox = __builtin_fmaf(p.fx, sx[i] / sz[i], p.cx), cooy = __builtin_fmaf(p.fy, sy[i] / sz[i], p.cy);
+        if (!(coox >= 0.f && cooy >= 0.f && coox < p.fcols && cooy < p.frows))
+          code[i] = 80;
+        else
+          px = (int)__builtin_floorf(coox), py = (int)__builtin_floorf(cooy);  // point-filtered fetch
+      }
+    }
+    d[i] = f4_at(p.vprev, p.vprev_pitch, py, px);  // pixel (0, 0) for a rejected one: read and ignored
+    nd[i] = f4_at(p.nprev, p.nprev_pitch, py, px);
+  }
+#pragma unroll
+  for (int i = 0; i < kPixelsPerLane; ++i)
+  {
+    if (!c.live[i])
+      break;
+    int cd = code[i];
+    if (cd == 0)
+    {
+      if (d[i].x != d[i].x)
+        cd = 120;
+      else
+      {
+        const float ex = sx[i] - d[i].x, ey = sy[i] - d[i].y, ez = sz[i] - d[i].z;
+        if (dot3(ex, ey, ez, ex, ey, ez) > p.dist2_thres)
+          cd = 160;
+        else
+        {
+          const float nsx = dot3(R[0], R[1], R[2], c.nc[i].x, c.nc[i].y, c.nc[i].z);
+          const float nsy = dot3(R[3], R[4], R[5], c.nc[i].x, c.nc[i].y, c.nc[i].z);
+          const float nsz = dot3(R[6], R[7], R[8], c.nc[i].x, c.nc[i].y, c.nc[i].z);
+          const float cosine = __builtin_fabsf(dot3(nsx, nsy, nsz, nd[i].x, nd[i].y, nd[i].z));
+          if (cosine < p.min_cosine)
+            cd = 200;
+        }
+      }
+    }
+
+    if (cd == 0)
+    {
+      // proj_icp.cu:354-359  row = [cross(s, n), n, dot(n, d - s)]
+      float row[7];
+      row[0] = sy[i] * nd[i].z - sz[i] * nd[i].y;
+      row[1] = sz[i] * nd[i].x - sx[i] * nd[i].z;
+      row[2] = sx[i] * nd[i].y - sy[i] * nd[i].x;
+      row[3] = nd[i].x, row[4] = nd[i].y, row[5] = nd[i].z;
+      row[6] = dot3(nd[i].x, nd[i].y, nd[i].z, d[i].x - sx[i], d[i].y - sy[i], d[i].z - sz[i]);
+      int k = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 7; ++b)
+          acc[k++] += row[a] * row[b];  // order of proj_icp.cu:122-335
+      acc[27] += 1.f;
+    }
+    else
+    {
+      acc[28] += cd == 40 ? 1.f : 0.f;
+      acc[29] += cd == 80 ? 1.f : 0.f;
+      acc[30] += cd == 120 ? 1.f : 0.f;
+      acc[31] += cd == 160 ? 1.f : 0.f;
+      acc[32] += cd == 200 ? 1.f : 0.f;
+    }
+  }
+}
+
+// The 33 sums of a 256-lane block from its lanes' sums: wave sums (in lane 63), then the block's four waves through
+// LDS (`lds` is this block's [4][kValues]); the caller synchronises, then lane k < kValues of the block holds value k
+// in block_value().
+__device__ __forceinline__ void block_sums_to_lds(float (&acc)[kValues], float (*lds)[kValues], int tid)
+{
+#pragma unroll
+  for (int k = 0; k < kValues; ++k)
+    acc[k] = wave_sum_lane63(acc[k]);
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane == 63)
+  {
+#pragma unroll
+    for (int k = 0; k < kValues; ++k)
+      lds[wave][k] = acc[k];
+  }
+}
+__device__ __forceinline__ float block_value(const float (*lds)[kValues], int k)
+{
+  return ((lds[0][k] + lds[1][k]) + lds[2][k]) + lds[3][k];
+}
+
 __global__ __launch_bounds__(256) void icp_accumulate_kernel(const IcpParams p, float* partial, int n_blocks)
 {
   float acc[kValues];
@@ -318,26 +461,8 @@ __global__ __launch_bounds__(256) void icp_accumulate_kernel(const IcpParams p, 
   for (int k = 0; k < kValues; ++k)
     acc[k] = 0.f;
 
-  // The four pixels of a lane are independent until their sums meet, and the kernel is latency-bound (one
-  // or two waves per SIMD, each pixel a chain load -> project -> gather): all four current-map loads go
-  // out together, then all four gathers, then the arithmetic -- pixel by pixel in the old order, so the
-  // sums are bit for bit what the one-pixel-at-a-time loop gave.  The current-map loads do not depend on
-  // the pose, so they are issued before the pose is worked out (device-resident loop) and fly meanwhile.
-  const int n_pixels = p.rows * p.cols;
-  const int base = (int)blockIdx.x * (256 * kPixelsPerLane) + (int)threadIdx.x;
-  bool live[kPixelsPerLane];
-  float4 s0[kPixelsPerLane], nc[kPixelsPerLane], d[kPixelsPerLane], nd[kPixelsPerLane];
-#pragma unroll
-  for (int i = 0; i < kPixelsPerLane; ++i)
-  {
-    const int pix = base + i * 256;
-    live[i] = pix < n_pixels;
-    const int pc = live[i] ? pix : (n_pixels > 0 ? n_pixels - 1 : 0);  // a dead lane re-reads the band's last pixel (an empty
-                                                                       // band of the sharded schedule: pixel (row0, 0), a valid row)
-    const int yr = pc / p.cols, x = pc - yr * p.cols, y = yr + p.row0;
-    s0[i] = f4_at(p.vcurr, p.vcurr_pitch, y, x);
-    nc[i] = f4_at(p.ncurr, p.ncurr_pitch, y, x);
-  }
+  CurrentMaps cur;
+  load_current(p, (int)blockIdx.x, (int)threadIdx.x, cur);
   float R[9], t[3];
   if (p.state)
   {
@@ -374,107 +499,15 @@ __global__ __launch_bounds__(256) void icp_accumulate_kernel(const IcpParams p, 
       t[i] = p.t[i];
   }
 
-  int code[kPixelsPerLane];
-  float sx[kPixelsPerLane], sy[kPixelsPerLane], sz[kPixelsPerLane];
-#pragma unroll
-  for (int i = 0; i < kPixelsPerLane; ++i)
-  {
-    // find_coresp, proj_icp.cu:74-102, up to the fetch of the destination point
-    code[i] = 0;
-    sx[i] = sy[i] = sz[i] = 0.f;
-    int px = 0, py = 0;
-    if (s0[i].x != s0[i].x)
-      code[i] = 40;
-    else
-    {
-      sx[i] = dot3(R[0], R[1], R[2], s0[i].x, s0[i].y, s0[i].z) + t[0];
-      sy[i] = dot3(R[3], R[4], R[5], s0[i].x, s0[i].y, s0[i].z) + t[1];
-      sz[i] = dot3(R[6], R[7], R[8], s0[i].x, s0[i].y, s0[i].z) + t[2];
-      if (sz[i] <= 0.f)
-        code[i] = 80;
-      else
-      {
-        const float coox = __builtin_fmaf(p.fx, sx[i] / sz[i], p.cx), cooy = __builtin_fmaf(p.fy, sy[i] / sz[i], p.cy);
-        if (!(coox >= 0.f && cooy >= 0.f && coox < p.fcols && cooy < p.frows))
-          code[i] = 80;
-        else
-          px = (int)__builtin_floorf(coox), py = (int)__builtin_floorf(cooy);  // point-filtered fetch
-      }
-    }
-    d[i] = f4_at(p.vprev, p.vprev_pitch, py, px);  // pixel (0, 0) for a rejected one: read and ignored
-    nd[i] = f4_at(p.nprev, p.nprev_pitch, py, px);
-  }
-#pragma unroll
-  for (int i = 0; i < kPixelsPerLane; ++i)
-  {
-    if (!live[i])
-      break;
-    int c = code[i];
-    if (c == 0)
-    {
-      if (d[i].x != d[i].x)
-        c = 120;
-      else
-      {
-        const float ex = sx[i] - d[i].x, ey = sy[i] - d[i].y, ez = sz[i] - d[i].z;
-        if (dot3(ex, ey, ez, ex, ey, ez) > p.dist2_thres)
-          c = 160;
-        else
-        {
-          const float nsx = dot3(R[0], R[1], R[2], nc[i].x, nc[i].y, nc[i].z);
-          const float nsy = dot3(R[3], R[4], R[5], nc[i].x, nc[i].y, nc[i].z);
-          const float nsz = dot3(R[6], R[7], R[8], nc[i].x, nc[i].y, nc[i].z);
-          const float cosine = __builtin_fabsf(dot3(nsx, nsy, nsz, nd[i].x, nd[i].y, nd[i].z));
-          if (cosine < p.min_cosine)
-            c = 200;
-        }
-      }
-    }
+  accumulate_pixels(p, R, t, cur, acc);
 
-    if (c == 0)
-    {
-      // proj_icp.cu:354-359  row = [cross(s, n), n, dot(n, d - s)]
-      float row[7];
-      row[0] = sy[i] * nd[i].z - sz[i] * nd[i].y;
-      row[1] = sz[i] * nd[i].x - sx[i] * nd[i].z;
-      row[2] = sx[i] * nd[i].y - sy[i] * nd[i].x;
-      row[3] = nd[i].x, row[4] = nd[i].y, row[5] = nd[i].z;
-      row[6] = dot3(nd[i].x, nd[i].y, nd[i].z, d[i].x - sx[i], d[i].y - sy[i], d[i].z - sz[i]);
-      int k = 0;
-#pragma unroll
-      for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int b = a; b < 7; ++b)
-          acc[k++] += row[a] * row[b];  // order of proj_icp.cu:122-335
-      acc[27] += 1.f;
-    }
-    else
-    {
-      acc[28] += c == 40 ? 1.f : 0.f;
-      acc[29] += c == 80 ? 1.f : 0.f;
-      acc[30] += c == 120 ? 1.f : 0.f;
-      acc[31] += c == 160 ? 1.f : 0.f;
-      acc[32] += c == 200 ? 1.f : 0.f;
-    }
-  }
-
-  // wave sums (in lane 63), then the four waves through LDS
-#pragma unroll
-  for (int k = 0; k < kValues; ++k)
-    acc[k] = wave_sum_lane63(acc[k]);
   __shared__ float lds[4][kValues];
-  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-  if (lane == 63)
-  {
-#pragma unroll
-    for (int k = 0; k < kValues; ++k)
-      lds[wave][k] = acc[k];
-  }
+  block_sums_to_lds(acc, lds, (int)threadIdx.x);
   __syncthreads();
   if (threadIdx.x < kValues)
   {
     const int k = (int)threadIdx.x;
-    partial[(size_t)k * n_blocks + blockIdx.x] = ((lds[0][k] + lds[1][k]) + lds[2][k]) + lds[3][k];
+    partial[(size_t)k * n_blocks + blockIdx.x] = block_value(lds, k);
   }
 }
 
@@ -514,6 +547,158 @@ __global__ __launch_bounds__(1024) void icp_solve_kernel(const float* partial, i
     {
       *host_out = st;
       __hip_atomic_store(host_ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+// ---- the whole schedule in ONE launch ------------------------------------------------------------------------
+// Of the 8-10 us a linearisation takes as a launch of its own, 6-7 are the grid-wide reduction through memory: the
+// block sums are stored, the kernel ends, the next one starts and loads them (time stamps).  Here
+// the workgroups stay: a workgroup of 512 lanes plays two of the 256-lane blocks above (the same pixels, the same
+// order of additions: the block sums are bit for bit those of icp_accumulate_kernel), stores each sum together
+// with the linearisation's tag as one 8-byte word into memory that no cache holds, and then reads ALL block sums
+// of that linearisation -- again and again until every word carries the tag -- adds them in the fixed order of
+// reduce_partials, solves, and goes on with the new pose.  One trip to memory out and one back instead of a kernel
+// boundary between them; no fence, no write-back or invalidation of any cache (the exchange words are the only
+// data that must be coherent, and they are never cached).  Two exchange buffers alternate: a workgroup can be at
+// most one linearisation ahead of the slowest, because it needs everybody's sums of linearisation j before it can
+// store its own of j + 1.  The poll is bounded: a workgroup that does not see the tags in about half a second (the
+// grid not resident as a whole, say) gives up with status 3, the others follow, and the host runs the chain of
+// launches instead.
+constexpr int kPersistLevels = 4;
+constexpr int kPersistBlocks = 2;  // 256-lane blocks a workgroup plays: 512 lanes, two waves per SIMD, 256 registers each
+constexpr int kPersistMaxBlocks = 320;  // 5 words per lane and value in the poll
+struct IcpPersist
+{
+  IcpParams level[kPersistLevels];  // in schedule order: coarse to fine
+  int iterations[kPersistLevels], n_blocks[kPersistLevels];
+  int n_levels;
+  IcpState init;
+  unsigned long long* exchange[2];  // kValues * kPersistMaxBlocks words each: (tag << 32) | float bits
+  unsigned tag0;
+  IcpState* state_out;
+  IcpState* host_out;
+  unsigned* host_ticket;
+  unsigned ticket;
+};
+
+// wave w of 8 adds values w, w + 8, ...: lane j takes the blocks j, j + 64, ... in order, then the wave sum -- the
+// order of reduce_partials.  Returns false if the tags did not come.
+__device__ __forceinline__ bool reduce_tagged(const unsigned long long* ex, int n_blocks, unsigned tag, float* sums)
+{
+  constexpr int kWaves = 4 * kPersistBlocks, kVals = (kValues + kWaves - 1) / kWaves, kDeep = kPersistMaxBlocks / 64;
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+  unsigned long long w[kVals][kDeep];
+  for (unsigned spin = 0;; ++spin)
+  {
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < kVals; ++i)
+#pragma unroll
+      for (int u = 0; u < kDeep; ++u)
+      {
+        const int k = wave + i * kWaves, b = lane + 64 * u;
+        const bool mine = k < kValues && b < n_blocks;
+        w[i][u] = mine ? __hip_atomic_load(ex + (k * n_blocks + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                       : ((unsigned long long)tag << 32);
+      }
+#pragma unroll
+    for (int i = 0; i < kVals; ++i)
+#pragma unroll
+      for (int u = 0; u < kDeep; ++u)
+        ok = ok && (unsigned)(w[i][u] >> 32) == tag;
+    if (__builtin_amdgcn_ballot_w64(!ok) == 0)
+      break;
+    if (spin > (1u << 18))
+      return false;
+    __builtin_amdgcn_s_sleep(2);
+  }
+#pragma unroll
+  for (int i = 0; i < kVals; ++i)
+  {
+    float v = 0.f;
+#pragma unroll
+    for (int u = 0; u < kDeep; ++u)
+      if (lane + 64 * u < n_blocks)
+        v += __uint_as_float((unsigned)w[i][u]);
+    const float r = wave_sum_lane63(v);
+    const int k = wave + i * kWaves;
+    if (lane == 63 && k < kValues)
+      sums[k] = r;
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(256 * kPersistBlocks) void icp_persistent_kernel(const IcpPersist q)
+{
+  __shared__ float sums[kValues];
+  __shared__ float lds[kPersistBlocks][4][kValues];
+  __shared__ int gave_up;
+  const int tid = (int)threadIdx.x & 255, sub = (int)threadIdx.x >> 8;
+  const int block = (int)blockIdx.x * kPersistBlocks + sub;  // the 256-lane block this part of the workgroup plays
+  if (threadIdx.x == 0)
+    gave_up = 0;
+  __syncthreads();
+  IcpState st = q.init;
+  int j = 0, prev_blocks = 0;  // linearisations started; blocks of the previous one
+
+  // previous linearisation: everybody's block sums -> the 33 sums -> the pose.  false: stop.
+  auto finish_previous = [&]() {
+    if (!reduce_tagged(q.exchange[(j - 1) & 1], prev_blocks, q.tag0 + (unsigned)(j - 1), sums))
+      gave_up = 1;
+    __syncthreads();
+    if (gave_up)
+    {
+      st.status = 3;
+      return false;
+    }
+    if (st.status == 0)
+      solve_update(sums, st);
+    __syncthreads();  // (sums is rewritten by the next call)
+    return st.status == 0;
+  };
+
+  bool running = true;
+#pragma unroll
+  for (int l = 0; l < kPersistLevels; ++l)
+  {
+    if (l >= q.n_levels || !running)
+      break;
+    const IcpParams& p = q.level[l];
+    const int n_blocks = q.n_blocks[l];
+    for (int it = 0; it < q.iterations[l] && running; ++it, ++j)
+    {
+      CurrentMaps cur;
+      load_current(p, block < n_blocks ? block : 0, tid, cur);
+      if (j > 0 && !finish_previous())
+      {
+        running = false;
+        break;
+      }
+      float acc[kValues];
+#pragma unroll
+      for (int k = 0; k < kValues; ++k)
+        acc[k] = 0.f;
+      if (block < n_blocks)
+        accumulate_pixels(p, st.R, st.t, cur, acc);
+      block_sums_to_lds(acc, lds[sub], tid);
+      __syncthreads();
+      if (tid < kValues && block < n_blocks)
+      {
+        const unsigned long long word = ((unsigned long long)(q.tag0 + (unsigned)j) << 32) | __float_as_uint(block_value(lds[sub], tid));
+        __hip_atomic_store(q.exchange[j & 1] + (tid * n_blocks + block), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      prev_blocks = n_blocks;
+    }
+  }
+  if (running && j > 0)
+    finish_previous();
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    *q.state_out = st;
+    if (q.host_out)
+    {
+      *q.host_out = st;
+      __hip_atomic_store(q.host_ticket, q.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -609,10 +794,130 @@ static int icp_scratch(yakhip_ctx* ctx, size_t need)
 // (Folding the reduce+solve into the SAME accumulate launch -- last workgroup by ticket -- was measured and is
 // slower, 0.52 ms: the device-scope release/acquire fences every workgroup then needs write back and
 // invalidate the XCD's L2, which costs more than a launch.)
+// One launch for the whole schedule (icp_persistent_kernel).  Returns 1 if it was not tried or gave up (the caller
+// runs the chain of launches), 0 with the result in place, < 0 / hipError on failure.
+static int launch_icp_persistent(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], float dist_thres,
+                                 float angle_thres, const yakhip_icp_level* levels, int n_levels, float R_out[9],
+                                 float t_out[3], int* status_out, int* iterations_out)
+{
+  if (!ctx->icp_persistent || !ctx->icp_poll)
+    return 1;
+  IcpPersist q;
+  int used = 0, max_blocks = 0;
+  unsigned n_lin = 0;
+  for (int l = n_levels - 1; l >= 0; --l)
+  {
+    const yakhip_icp_level& L = levels[l];
+    if (L.iterations <= 0)
+      continue;
+    const long long n_pixels = (long long)L.rows * L.cols;
+    const long long nb = (n_pixels + 256 * kPixelsPerLane - 1) / (256 * kPixelsPerLane);
+    if (used == kPersistLevels || nb > kPersistMaxBlocks || n_lin + (unsigned)L.iterations > 4096u)
+      return 1;
+    IcpParams& p = q.level[used];
+    p.state = nullptr, p.state_out = nullptr, p.prev_partial = nullptr, p.prev_blocks = 0;
+    for (int i = 0; i < 9; ++i)
+      p.R[i] = 0.f;
+    for (int i = 0; i < 3; ++i)
+      p.t[i] = 0.f;
+    const int div = 1 << l;  // projective_icp.cpp:16-22
+    p.fx = intr[0] / div, p.fy = intr[1] / div, p.cx = intr[2] / div, p.cy = intr[3] / div;
+    p.frows = (float)L.rows, p.fcols = (float)L.cols;
+    p.min_cosine = (float)cos((double)angle_thres);
+    p.dist2_thres = dist_thres * dist_thres;
+    p.vcurr = (const uint8_t*)L.vcurr, p.ncurr = (const uint8_t*)L.ncurr;
+    p.vprev = (const uint8_t*)L.vprev, p.nprev = (const uint8_t*)L.nprev;
+    p.vcurr_pitch = (uint32_t)L.vcurr_pitch, p.ncurr_pitch = (uint32_t)L.ncurr_pitch;
+    p.vprev_pitch = (uint32_t)L.vprev_pitch, p.nprev_pitch = (uint32_t)L.nprev_pitch;
+    p.rows = L.rows, p.cols = L.cols, p.row0 = 0;
+    q.iterations[used] = L.iterations;
+    q.n_blocks[used] = (int)nb;
+    max_blocks = nb > max_blocks ? (int)nb : max_blocks;
+    n_lin += (unsigned)L.iterations;
+    ++used;
+  }
+  if (used == 0)
+    return 1;
+  for (int i = used; i < kPersistLevels; ++i)
+  {
+    q.level[i] = q.level[0];
+    q.iterations[i] = 0, q.n_blocks[i] = 0;
+  }
+  q.n_levels = used;
+  // the exchange words live in memory no cache holds; allocated once per context, with the state slot behind them
+  const size_t words = (size_t)kValues * kPersistMaxBlocks;
+  if (!ctx->icp_exchange)
+  {
+    void* mem = nullptr;
+    if (hipExtMallocWithFlags(&mem, 2 * words * 8 + 256, hipDeviceMallocUncached) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      ctx->icp_persistent = 0;  // this runtime has no such memory: the chain of launches it is
+      return 1;
+    }
+    ctx->icp_exchange = mem;
+    YAKHIP_TRY(hipMemsetAsync(mem, 0, 2 * words * 8 + 256, ctx->stream));
+    ctx->icp_tag = 1;
+  }
+  int rc = icp_scratch(ctx, 256);
+  if (rc != 0)
+    return rc;
+  if (ctx->icp_tag > 0xffffffffu - n_lin - 1u)
+    ctx->icp_tag = 1;  // (tags in flight are never older than one call: reuse after 2^32 is safe, 0 stays "never written")
+  q.exchange[0] = (unsigned long long*)ctx->icp_exchange;
+  q.exchange[1] = q.exchange[0] + words;
+  q.tag0 = ctx->icp_tag;
+  ctx->icp_tag += n_lin;
+  for (int i = 0; i < 9; ++i)
+    q.init.R[i] = R[i];
+  for (int i = 0; i < 3; ++i)
+    q.init.t[i] = t[i];
+  q.init.status = 0, q.init.iterations = 0;
+  q.state_out = (IcpState*)((char*)ctx->icp_exchange + 2 * words * 8);
+  IcpState* result = (IcpState*)((char*)ctx->icp_pinned + 128);
+  unsigned* ticket_at = (unsigned*)((char*)ctx->icp_pinned + 192);
+  q.host_out = result, q.host_ticket = ticket_at, q.ticket = ++ctx->icp_ticket;
+  const unsigned grid = (unsigned)((max_blocks + kPersistBlocks - 1) / kPersistBlocks);
+  hipLaunchKernelGGL(icp_persistent_kernel, dim3(grid), dim3(256 * kPersistBlocks), 0, ctx->stream, q);
+  YAKHIP_TRY(hipGetLastError());
+  bool arrived = false;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 1; !arrived; ++spins)
+  {
+    arrived = __atomic_load_n(ticket_at, __ATOMIC_ACQUIRE) == q.ticket;
+    if (!arrived && (spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(4))
+      break;
+  }
+  if (!arrived)
+  {
+    YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (__atomic_load_n(ticket_at, __ATOMIC_ACQUIRE) != q.ticket)
+      return fail(YAKHIP_EINVAL, "icp_estimate: the one-launch kernel finished without a result");
+  }
+  if (result->status == 3)
+  {
+    ctx->icp_persistent_gave_up += 1;
+    return 1;
+  }
+  for (int i = 0; i < 9; ++i)
+    R_out[i] = result->R[i];
+  for (int i = 0; i < 3; ++i)
+    t_out[i] = result->t[i];
+  *status_out = result->status;
+  *iterations_out = result->iterations;
+  return 0;
+}
+
 int launch_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], float dist_thres,
                         float angle_thres, const yakhip_icp_level* levels, int n_levels, float R_out[9], float t_out[3],
                         int* status_out, int* iterations_out)
 {
+  {
+    const int rc = launch_icp_persistent(ctx, R, t, intr, dist_thres, angle_thres, levels, n_levels, R_out, t_out, status_out,
+                                         iterations_out);
+    if (rc != 1)
+      return rc;
+  }
   int max_blocks = 1;
   long long n_launches = 0;
   for (int l = 0; l < n_levels; ++l)
