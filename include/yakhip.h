@@ -110,15 +110,11 @@ const char* yakhip_last_error(void);
  * shallow to deep, 1 shallow / deep in turn, 3 deepest first), "chunk_min" / "chunk_ramp" (graded z-chunks of a volume walked from
  * layer 0: a chunk that starts at layer zs is about zs / ramp layers long, at least chunk_min; 0 = auto, ramp -1 = all alike),
  * "icp_poll" (0/1: yakhip_icp_estimate polls pinned memory for its result / copies and
- * synchronises), "icp_persistent" (0/1: yakhip_icp_estimate runs its schedule in one launch / one launch per linearisation), "surface_skip" (0/1: the ray cast consults / ignores yakhip_volume.surface_map),
+ * synchronises), "surface_skip" (0/1: the ray cast consults / ignores yakhip_volume.surface_map),
  * "brick_stats" (0/1, see yakhip_ctx_brick_stats), "composite_capacity" (list slots of yakhip_raycast_sharded's second step, 0 = auto),
  * "zu" (ignored).
  * Unknown key or value -> YAKHIP_EINVAL. */
 int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value);
-/* Engine counters (no counterpart in the reference).  Keys: "icp_persistent_gave_up" -- yakhip_icp_estimate calls
- * whose one-launch kernel could not finish (its workgroups did not see each other's sums in time) and whose
- * result therefore came from one launch per linearisation; the same result, later.  Unknown key -> YAKHIP_EINVAL. */
-int yakhip_ctx_get_counter(yakhip_ctx* ctx, const char* key, unsigned long long* value);
 /* Measurement aid with no counterpart in the reference (its only timers are the never-invoked
  * ScopeTime/SampledScopeTime, yak/src/kfusion/core.cpp:236-260).  After
  * yakhip_ctx_set_option(ctx, "kernel_timing", 1) every integrate / raycast / marching-cubes kernel launch is bracketed by a

@@ -325,33 +325,6 @@ def test_icp_estimate_device_loop_equals_host_loop(gpu_ctx):
     assert Rd2 == Rd and td2 == td
 
 
-def test_icp_estimate_in_one_launch_equals_the_chain_of_launches(gpu_ctx):
-    """The whole schedule in one launch (workgroups exchange their block sums through uncached memory, option
-    icp_persistent, the default) against one launch per linearisation: the same block sums added in the same order, so
-    the poses are the same bits -- over many frame pairs, schedules and calls in a row (the exchange buffers alternate
-    and carry a tag per linearisation: a stale word from an earlier linearisation or call must never be taken)."""
-    rng = np.random.default_rng(5)
-    for pair, (a, b) in enumerate([(60, 62), (10, 11), (150, 153), (255, 257), (299, 0)]):
-        prev = [level_maps(a, l) for l in range(3)]
-        curr = [level_maps(b, l) for l in range(3)]
-        dev = [[dev_f4(x) for x in (curr[l][0], curr[l][1], prev[l][0], prev[l][1])] for l in range(3)]
-        shapes = [curr[l][0].shape[:2] for l in range(3)]
-        for its in [(4, 5, 10), (1, 0, 0), (0, 0, 3), (2, 7, 1), (10, 5, 4)][:5 if pair < 2 else 2]:
-            levels = [(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[0].stride(0) * 4, shapes[l][0],
-                       shapes[l][1], it) for l, (d, it) in enumerate(zip(dev, its))]
-            R0 = np.eye(3) if pair % 2 == 0 else synth.look_at(np.zeros(3), np.array([0.01, -0.02, 1.0]))[0]
-            t0 = rng.uniform(-0.01, 0.01, 3)
-            args = (np.float32(R0).reshape(-1), np.float32(t0), synth.INTR, 0.1, math.radians(30.0), levels)
-            gpu_ctx.set_option("icp_persistent", 0)
-            try:
-                want = gpu_ctx.icp_estimate(*args)
-            finally:
-                gpu_ctx.set_option("icp_persistent", 1)
-            for _ in range(6 if pair == 0 else 2):
-                assert gpu_ctx.icp_estimate(*args) == want
-    assert gpu_ctx.counter("icp_persistent_gave_up") == 0      # (it really was the one launch that answered)
-
-
 def test_icp_estimate_weakly_constrained_view_stays_on_the_device(gpu_ctx):
     """Frames 250-260 of the orbit: the eigenvalues of the normal matrix are spread so far that the device
     solve's first certificate (AM-GM bound on lambda_min, icp.hip solve_update) fails although lambda_min is

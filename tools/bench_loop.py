@@ -16,15 +16,12 @@ def main():
     ap.add_argument("--frames", type=int, default=60)
     ap.add_argument("--no-icp", action="store_true")
     ap.add_argument("--host-icp", action="store_true", help="one blocking linearisation at a time, numpy solve")
-    ap.add_argument("--chain", action="store_true", help="one launch per ICP linearisation instead of one for the schedule")
     ap.add_argument("--no-poll", action="store_true", help="yakhip_icp_estimate copies and synchronises instead of polling")
     args = ap.parse_args()
     from yak_amd import capi
     from yak_amd.loop import run_kinfu_loop
 
     ctx = capi.Context(0)
-    if args.chain:
-        ctx.set_option("icp_persistent", 0)
     if args.no_poll:
         ctx.set_option("icp_poll", 0)
     run_kinfu_loop(ctx, args.n, 8, "device")  # warm-up

@@ -16,7 +16,7 @@ EXPORTS = [
     "yakhip_ctx_kernel_time", "yakhip_ctx_kernel_times", "yakhip_ctx_brick_stats", "yakhip_selftest_division",
     "yakhip_malloc", "yakhip_malloc_pitch", "yakhip_free", "yakhip_upload", "yakhip_download",
     "yakhip_upload_2d", "yakhip_download_2d", "yakhip_copy", "yakhip_copy_2d",
-    "yakhip_ctx_get_counter", "yakhip_clear_volume", "yakhip_surface_map_bytes", "yakhip_surface_map_rebuild", "yakhip_compute_dists", "yakhip_integrate", "yakhip_integrate_static",
+    "yakhip_clear_volume", "yakhip_surface_map_bytes", "yakhip_surface_map_rebuild", "yakhip_compute_dists", "yakhip_integrate", "yakhip_integrate_static",
     "yakhip_integrate_batch",
     "yakhip_raycast_points", "yakhip_raycast_depth", "yakhip_raycast_slab", "yakhip_raycast_resolve", "yakhip_raycast_halo",
     "yakhip_bilateral_filter", "yakhip_truncate_depth", "yakhip_depth_pyramid", "yakhip_compute_points_normals",
@@ -111,7 +111,6 @@ def load():
         "yakhip_download_2d": [vp, vp, sz, vp, sz, sz, sz],
         "yakhip_copy": [vp, vp, vp, sz],
         "yakhip_copy_2d": [vp, vp, sz, vp, sz, sz, sz],
-        "yakhip_ctx_get_counter": [vp, C.c_char_p, C.POINTER(C.c_ulonglong)],
         "yakhip_clear_volume": [vp, volp],
         "yakhip_surface_map_bytes": [volp, C.POINTER(sz)],
         "yakhip_surface_map_rebuild": [vp, volp],
@@ -243,11 +242,6 @@ class Context:
         _chk(load().yakhip_ctx_synchronize(self._h))
 
     # ---- hot path; pointers are raw device addresses (ints) ----
-    def counter(self, key):
-        v = C.c_ulonglong(0)
-        _chk(load().yakhip_ctx_get_counter(self._h, key.encode(), C.byref(v)))
-        return v.value
-
     def clear_volume(self, vol):
         _chk(load().yakhip_clear_volume(self._h, C.byref(vol)))
 

@@ -152,10 +152,6 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->icp_pinned = nullptr;
   ctx->icp_ticket = 0;
   ctx->icp_poll = 1;
-  ctx->icp_persistent = 1;
-  ctx->icp_persistent_gave_up = 0;
-  ctx->icp_exchange = nullptr;
-  ctx->icp_tag = 1;
   ctx->mc_scratch = nullptr;
   ctx->mc_scratch_bytes = 0;
   ctx->mc_pinned = nullptr;
@@ -201,8 +197,6 @@ int yakhip_ctx_destroy(yakhip_ctx* ctx)
       (void)hipFree(ctx->icp_scratch);
     if (ctx->icp_pinned)
       (void)hipHostFree(ctx->icp_pinned);
-    if (ctx->icp_exchange)
-      (void)hipFree(ctx->icp_exchange);
     if (ctx->mc_scratch)
       (void)hipFree(ctx->mc_scratch);
     if (ctx->mc_pinned)
@@ -295,11 +289,6 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
     ctx->chunk_order = (int)value;
     return 0;
   }
-  if (strcmp(key, "icp_persistent") == 0)
-  {
-    ctx->icp_persistent = value != 0;
-    return 0;
-  }
   if (strcmp(key, "icp_poll") == 0)
   {
     ctx->icp_poll = value != 0;
@@ -382,18 +371,6 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
     return 0;
   }
   return fail(YAKHIP_EINVAL, "unknown option '%s'", key);
-}
-
-int yakhip_ctx_get_counter(yakhip_ctx* ctx, const char* key, unsigned long long* value)
-{
-  if (!ctx || !key || !value)
-    return fail(YAKHIP_EINVAL, "ctx_get_counter: null argument");
-  if (strcmp(key, "icp_persistent_gave_up") == 0)
-  {
-    *value = ctx->icp_persistent_gave_up;
-    return 0;
-  }
-  return fail(YAKHIP_EINVAL, "ctx_get_counter: unknown key '%s'", key);
 }
 
 int yakhip_ctx_kernel_time(yakhip_ctx* ctx, double* total_ms, int* launches)

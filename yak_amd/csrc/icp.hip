@@ -550,158 +550,6 @@ __global__ __launch_bounds__(1024) void icp_solve_kernel(const float* partial, i
     }
   }
 }
-// ---- the whole schedule in ONE launch ------------------------------------------------------------------------
-// Of the 8-10 us a linearisation takes as a launch of its own, 6-7 are the grid-wide reduction through memory: the
-// block sums are stored, the kernel ends, the next one starts and loads them (time stamps).  Here
-// the workgroups stay: a workgroup of 512 lanes plays two of the 256-lane blocks above (the same pixels, the same
-// order of additions: the block sums are bit for bit those of icp_accumulate_kernel), stores each sum together
-// with the linearisation's tag as one 8-byte word into memory that no cache holds, and then reads ALL block sums
-// of that linearisation -- again and again until every word carries the tag -- adds them in the fixed order of
-// reduce_partials, solves, and goes on with the new pose.  One trip to memory out and one back instead of a kernel
-// boundary between them; no fence, no write-back or invalidation of any cache (the exchange words are the only
-// data that must be coherent, and they are never cached).  Two exchange buffers alternate: a workgroup can be at
-// most one linearisation ahead of the slowest, because it needs everybody's sums of linearisation j before it can
-// store its own of j + 1.  The poll is bounded: a workgroup that does not see the tags in about half a second (the
-// grid not resident as a whole, say) gives up with status 3, the others follow, and the host runs the chain of
-// launches instead.
-constexpr int kPersistLevels = 4;
-constexpr int kPersistBlocks = 2;  // 256-lane blocks a workgroup plays: 512 lanes, two waves per SIMD, 256 registers each
-constexpr int kPersistMaxBlocks = 320;  // 5 words per lane and value in the poll
-struct IcpPersist
-{
-  IcpParams level[kPersistLevels];  // in schedule order: coarse to fine
-  int iterations[kPersistLevels], n_blocks[kPersistLevels];
-  int n_levels;
-  IcpState init;
-  unsigned long long* exchange[2];  // kValues * kPersistMaxBlocks words each: (tag << 32) | float bits
-  unsigned tag0;
-  IcpState* state_out;
-  IcpState* host_out;
-  unsigned* host_ticket;
-  unsigned ticket;
-};
-
-// wave w of 8 adds values w, w + 8, ...: lane j takes the blocks j, j + 64, ... in order, then the wave sum -- the
-// order of reduce_partials.  Returns false if the tags did not come.
-__device__ __forceinline__ bool reduce_tagged(const unsigned long long* ex, int n_blocks, unsigned tag, float* sums)
-{
-  constexpr int kWaves = 4 * kPersistBlocks, kVals = (kValues + kWaves - 1) / kWaves, kDeep = kPersistMaxBlocks / 64;
-  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-  unsigned long long w[kVals][kDeep];
-  for (unsigned spin = 0;; ++spin)
-  {
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < kVals; ++i)
-#pragma unroll
-      for (int u = 0; u < kDeep; ++u)
-      {
-        const int k = wave + i * kWaves, b = lane + 64 * u;
-        const bool mine = k < kValues && b < n_blocks;
-        w[i][u] = mine ? __hip_atomic_load(ex + (k * n_blocks + b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                       : ((unsigned long long)tag << 32);
-      }
-#pragma unroll
-    for (int i = 0; i < kVals; ++i)
-#pragma unroll
-      for (int u = 0; u < kDeep; ++u)
-        ok = ok && (unsigned)(w[i][u] >> 32) == tag;
-    if (__builtin_amdgcn_ballot_w64(!ok) == 0)
-      break;
-    if (spin > (1u << 18))
-      return false;
-    __builtin_amdgcn_s_sleep(2);
-  }
-#pragma unroll
-  for (int i = 0; i < kVals; ++i)
-  {
-    float v = 0.f;
-#pragma unroll
-    for (int u = 0; u < kDeep; ++u)
-      if (lane + 64 * u < n_blocks)
-        v += __uint_as_float((unsigned)w[i][u]);
-    const float r = wave_sum_lane63(v);
-    const int k = wave + i * kWaves;
-    if (lane == 63 && k < kValues)
-      sums[k] = r;
-  }
-  return true;
-}
-
-__global__ __launch_bounds__(256 * kPersistBlocks) void icp_persistent_kernel(const IcpPersist q)
-{
-  __shared__ float sums[kValues];
-  __shared__ float lds[kPersistBlocks][4][kValues];
-  __shared__ int gave_up;
-  const int tid = (int)threadIdx.x & 255, sub = (int)threadIdx.x >> 8;
-  const int block = (int)blockIdx.x * kPersistBlocks + sub;  // the 256-lane block this part of the workgroup plays
-  if (threadIdx.x == 0)
-    gave_up = 0;
-  __syncthreads();
-  IcpState st = q.init;
-  int j = 0, prev_blocks = 0;  // linearisations started; blocks of the previous one
-
-  // previous linearisation: everybody's block sums -> the 33 sums -> the pose.  false: stop.
-  auto finish_previous = [&]() {
-    if (!reduce_tagged(q.exchange[(j - 1) & 1], prev_blocks, q.tag0 + (unsigned)(j - 1), sums))
-      gave_up = 1;
-    __syncthreads();
-    if (gave_up)
-    {
-      st.status = 3;
-      return false;
-    }
-    if (st.status == 0)
-      solve_update(sums, st);
-    __syncthreads();  // (sums is rewritten by the next call)
-    return st.status == 0;
-  };
-
-  bool running = true;
-#pragma unroll
-  for (int l = 0; l < kPersistLevels; ++l)
-  {
-    if (l >= q.n_levels || !running)
-      break;
-    const IcpParams& p = q.level[l];
-    const int n_blocks = q.n_blocks[l];
-    for (int it = 0; it < q.iterations[l] && running; ++it, ++j)
-    {
-      CurrentMaps cur;
-      load_current(p, block < n_blocks ? block : 0, tid, cur);
-      if (j > 0 && !finish_previous())
-      {
-        running = false;
-        break;
-      }
-      float acc[kValues];
-#pragma unroll
-      for (int k = 0; k < kValues; ++k)
-        acc[k] = 0.f;
-      if (block < n_blocks)
-        accumulate_pixels(p, st.R, st.t, cur, acc);
-      block_sums_to_lds(acc, lds[sub], tid);
-      __syncthreads();
-      if (tid < kValues && block < n_blocks)
-      {
-        const unsigned long long word = ((unsigned long long)(q.tag0 + (unsigned)j) << 32) | __float_as_uint(block_value(lds[sub], tid));
-        __hip_atomic_store(q.exchange[j & 1] + (tid * n_blocks + block), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      prev_blocks = n_blocks;
-    }
-  }
-  if (running && j > 0)
-    finish_previous();
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-  {
-    *q.state_out = st;
-    if (q.host_out)
-    {
-      *q.host_out = st;
-      __hip_atomic_store(q.host_ticket, q.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-}
 }  // namespace
 
 static int icp_scratch(yakhip_ctx* ctx, size_t need);
@@ -794,130 +642,10 @@ static int icp_scratch(yakhip_ctx* ctx, size_t need)
 // (Folding the reduce+solve into the SAME accumulate launch -- last workgroup by ticket -- was measured and is
 // slower, 0.52 ms: the device-scope release/acquire fences every workgroup then needs write back and
 // invalidate the XCD's L2, which costs more than a launch.)
-// One launch for the whole schedule (icp_persistent_kernel).  Returns 1 if it was not tried or gave up (the caller
-// runs the chain of launches), 0 with the result in place, < 0 / hipError on failure.
-static int launch_icp_persistent(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], float dist_thres,
-                                 float angle_thres, const yakhip_icp_level* levels, int n_levels, float R_out[9],
-                                 float t_out[3], int* status_out, int* iterations_out)
-{
-  if (!ctx->icp_persistent || !ctx->icp_poll)
-    return 1;
-  IcpPersist q;
-  int used = 0, max_blocks = 0;
-  unsigned n_lin = 0;
-  for (int l = n_levels - 1; l >= 0; --l)
-  {
-    const yakhip_icp_level& L = levels[l];
-    if (L.iterations <= 0)
-      continue;
-    const long long n_pixels = (long long)L.rows * L.cols;
-    const long long nb = (n_pixels + 256 * kPixelsPerLane - 1) / (256 * kPixelsPerLane);
-    if (used == kPersistLevels || nb > kPersistMaxBlocks || n_lin + (unsigned)L.iterations > 4096u)
-      return 1;
-    IcpParams& p = q.level[used];
-    p.state = nullptr, p.state_out = nullptr, p.prev_partial = nullptr, p.prev_blocks = 0;
-    for (int i = 0; i < 9; ++i)
-      p.R[i] = 0.f;
-    for (int i = 0; i < 3; ++i)
-      p.t[i] = 0.f;
-    const int div = 1 << l;  // projective_icp.cpp:16-22
-    p.fx = intr[0] / div, p.fy = intr[1] / div, p.cx = intr[2] / div, p.cy = intr[3] / div;
-    p.frows = (float)L.rows, p.fcols = (float)L.cols;
-    p.min_cosine = (float)cos((double)angle_thres);
-    p.dist2_thres = dist_thres * dist_thres;
-    p.vcurr = (const uint8_t*)L.vcurr, p.ncurr = (const uint8_t*)L.ncurr;
-    p.vprev = (const uint8_t*)L.vprev, p.nprev = (const uint8_t*)L.nprev;
-    p.vcurr_pitch = (uint32_t)L.vcurr_pitch, p.ncurr_pitch = (uint32_t)L.ncurr_pitch;
-    p.vprev_pitch = (uint32_t)L.vprev_pitch, p.nprev_pitch = (uint32_t)L.nprev_pitch;
-    p.rows = L.rows, p.cols = L.cols, p.row0 = 0;
-    q.iterations[used] = L.iterations;
-    q.n_blocks[used] = (int)nb;
-    max_blocks = nb > max_blocks ? (int)nb : max_blocks;
-    n_lin += (unsigned)L.iterations;
-    ++used;
-  }
-  if (used == 0)
-    return 1;
-  for (int i = used; i < kPersistLevels; ++i)
-  {
-    q.level[i] = q.level[0];
-    q.iterations[i] = 0, q.n_blocks[i] = 0;
-  }
-  q.n_levels = used;
-  // the exchange words live in memory no cache holds; allocated once per context, with the state slot behind them
-  const size_t words = (size_t)kValues * kPersistMaxBlocks;
-  if (!ctx->icp_exchange)
-  {
-    void* mem = nullptr;
-    if (hipExtMallocWithFlags(&mem, 2 * words * 8 + 256, hipDeviceMallocUncached) != hipSuccess)
-    {
-      (void)hipGetLastError();
-      ctx->icp_persistent = 0;  // this runtime has no such memory: the chain of launches it is
-      return 1;
-    }
-    ctx->icp_exchange = mem;
-    YAKHIP_TRY(hipMemsetAsync(mem, 0, 2 * words * 8 + 256, ctx->stream));
-    ctx->icp_tag = 1;
-  }
-  int rc = icp_scratch(ctx, 256);
-  if (rc != 0)
-    return rc;
-  if (ctx->icp_tag > 0xffffffffu - n_lin - 1u)
-    ctx->icp_tag = 1;  // (tags in flight are never older than one call: reuse after 2^32 is safe, 0 stays "never written")
-  q.exchange[0] = (unsigned long long*)ctx->icp_exchange;
-  q.exchange[1] = q.exchange[0] + words;
-  q.tag0 = ctx->icp_tag;
-  ctx->icp_tag += n_lin;
-  for (int i = 0; i < 9; ++i)
-    q.init.R[i] = R[i];
-  for (int i = 0; i < 3; ++i)
-    q.init.t[i] = t[i];
-  q.init.status = 0, q.init.iterations = 0;
-  q.state_out = (IcpState*)((char*)ctx->icp_exchange + 2 * words * 8);
-  IcpState* result = (IcpState*)((char*)ctx->icp_pinned + 128);
-  unsigned* ticket_at = (unsigned*)((char*)ctx->icp_pinned + 192);
-  q.host_out = result, q.host_ticket = ticket_at, q.ticket = ++ctx->icp_ticket;
-  const unsigned grid = (unsigned)((max_blocks + kPersistBlocks - 1) / kPersistBlocks);
-  hipLaunchKernelGGL(icp_persistent_kernel, dim3(grid), dim3(256 * kPersistBlocks), 0, ctx->stream, q);
-  YAKHIP_TRY(hipGetLastError());
-  bool arrived = false;
-  const auto t0 = std::chrono::steady_clock::now();
-  for (unsigned spins = 1; !arrived; ++spins)
-  {
-    arrived = __atomic_load_n(ticket_at, __ATOMIC_ACQUIRE) == q.ticket;
-    if (!arrived && (spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(4))
-      break;
-  }
-  if (!arrived)
-  {
-    YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (__atomic_load_n(ticket_at, __ATOMIC_ACQUIRE) != q.ticket)
-      return fail(YAKHIP_EINVAL, "icp_estimate: the one-launch kernel finished without a result");
-  }
-  if (result->status == 3)
-  {
-    ctx->icp_persistent_gave_up += 1;
-    return 1;
-  }
-  for (int i = 0; i < 9; ++i)
-    R_out[i] = result->R[i];
-  for (int i = 0; i < 3; ++i)
-    t_out[i] = result->t[i];
-  *status_out = result->status;
-  *iterations_out = result->iterations;
-  return 0;
-}
-
 int launch_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], float dist_thres,
                         float angle_thres, const yakhip_icp_level* levels, int n_levels, float R_out[9], float t_out[3],
                         int* status_out, int* iterations_out)
 {
-  {
-    const int rc = launch_icp_persistent(ctx, R, t, intr, dist_thres, angle_thres, levels, n_levels, R_out, t_out, status_out,
-                                         iterations_out);
-    if (rc != 1)
-      return rc;
-  }
   int max_blocks = 1;
   long long n_launches = 0;
   for (int l = 0; l < n_levels; ++l)

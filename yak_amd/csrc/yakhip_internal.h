@@ -40,10 +40,6 @@ struct yakhip_ctx
   void* icp_pinned;    // ICP: pinned host mirror of the 33 values / the state; +128 the state and +192 the ticket icp_solve_kernel writes
   unsigned icp_ticket; // tickets handed out to yakhip_icp_estimate calls
   int icp_poll;        // the host polls that ticket (default) / copies and synchronises
-  int icp_persistent;  // yakhip_icp_estimate runs its whole schedule in one launch (default) / one launch per linearisation
-  unsigned icp_persistent_gave_up;  // calls whose one-launch kernel gave up (the chain of launches took over)
-  void* icp_exchange;  // uncached device memory: the block sums the workgroups of that launch exchange, the final state
-  unsigned icp_tag;    // next linearisation tag
   void* mc_scratch;    // marching cubes: tile counts, tile offsets, total (device)
   size_t mc_scratch_bytes;
   void* mc_pinned;     // marching cubes: pinned host copy of the total
