@@ -133,6 +133,7 @@ int main(int argc, char** argv)
       t0 = now();
       for (int f = 0; f < frames; ++f)
       {
+        kinfu.beginFrame();
         d.upload(depth[f].data(), (size_t)p.cols * 2, p.rows, p.cols);
         const bool ok = kinfu(Affine3f::Identity(), Affine3f::Identity(), Affine3f::Identity(), d);
         if (!ok && f > 0)

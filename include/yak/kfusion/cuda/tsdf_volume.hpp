@@ -51,6 +51,11 @@ public:
 
   void swap(CudaData& data);
 
+  /** integrate() waits for the device before it returns, as the reference's does (tsdf_volume.cu:139); a caller that
+   *  keeps the ray-distance image alive until the work is done (KinFu does) may switch the wait off.  No counterpart
+   *  in the reference. */
+  void setBlockingIntegrate(bool blocking);
+
   // ---- z-slab sharding (no counterpart in the reference; world == 1 leaves everything above as it is) ----
   /** Layers [z0, z1) of the volume this object OWNS on the calling thread's rank (cuda::currentShard()). */
   void ownedLayers(int& z0, int& z1) const;
@@ -80,6 +85,7 @@ private:
   void freshSurfaceMap();      // recompute the surface map if voxels may have been written behind the class's back
 
   int held_z0_, held_z1_;          // layers in data_ (0, dims[2] on one GPU)
+  bool blocking_integrate_;
   bool map_stale_;                 // data() / swap() handed the voxels out since the map was last known good
   CudaData surface_map_;           // one bit per 16^3 brick of the held layers (include/yakhip.h: yakhip_volume.surface_map)
   DeviceArray2D<int> keys_;        // sharded ray cast: the march-ending pair of every pixel

@@ -99,6 +99,13 @@ public:
    *  used by the multi-GPU tests to compare ranks. */
   void downloadModelMaps(void* points_out, void* normals_out) const;
 
+  /** True if operator() prepares a frame on the context's second stream (include/yakhip.h, yakhip_ctx_side_begin):
+   *  a caller that uploads the frame itself does so after yakhip_ctx_side_begin, and operator() takes it from there. */
+  bool overlapping() const { return overlap_; }
+  /** Opens that section (nothing if not overlapping): call it before uploading the frame operator() is about to get,
+   *  so that the copy does not queue up behind the integrate and ray cast of the frame before. */
+  void beginFrame();
+
 private:
   void allocate_buffers();
 
@@ -106,7 +113,8 @@ private:
   KinFuParams params_;
   std::vector<Affine3f> poses_;
 
-  cuda::Dists dists_;
+  cuda::Dists dists_, dists_alt_;  // in turn: frame f + 1's is written while frame f's is still being integrated
+  bool overlap_;                   // pre-processing on the context's second stream, no wait at the end of a frame
   cuda::Frame curr_, prev_;
   cuda::Cloud points_;
   cuda::Normals normals_;

@@ -93,6 +93,21 @@ int yakhip_ctx_destroy(yakhip_ctx* ctx);
 int yakhip_ctx_set_stream(yakhip_ctx* ctx, void* hip_stream);
 /* Go back to the context's own non-blocking stream. */
 int yakhip_ctx_use_own_stream(yakhip_ctx* ctx);
+/* The hipStream_t calls are currently enqueued on (the context's own, a borrowed one, or the side stream below):
+ * for callers that record their own events or launch their own kernels in order with the library's. */
+int yakhip_ctx_stream(yakhip_ctx* ctx, void** hip_stream);
+/* A second stream of the context (no counterpart in the reference, which launches everything on the default
+ * stream).  Calls made between yakhip_ctx_side_begin and yakhip_ctx_side_end are enqueued on it: they may run
+ * at the same time as what the context's stream was given since the PREVIOUS yakhip_ctx_side_end (they wait for
+ * everything before that), and everything enqueued AFTER yakhip_ctx_side_end runs after both.  For work that does
+ * not touch what those calls read or write -- a fusion loop prepares frame f + 1 (ray distances, bilateral
+ * filter, pyramids, point / normal maps) while the integrate and ray cast of frame f are still running; buffers
+ * written there and read by frame f's main-stream work (the ray-distance image) alternate between two.
+ * Blocking calls made in between wait for the side stream only.  A second yakhip_ctx_side_begin inside a
+ * section does nothing: whoever calls yakhip_ctx_side_end next ends it (a server uploads the frame in the section
+ * that its tracker then continues and ends). */
+int yakhip_ctx_side_begin(yakhip_ctx* ctx);
+int yakhip_ctx_side_end(yakhip_ctx* ctx);
 /* Replaces cuda::waitAllDefaultStream (yak/src/kfusion/imgproc.cpp:21) and the
  * cudaDeviceSynchronize at yak/src/cuda/tsdf_volume.cu:139. */
 int yakhip_ctx_synchronize(yakhip_ctx* ctx);

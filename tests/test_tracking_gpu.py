@@ -15,7 +15,7 @@ import pytest
 torch = pytest.importorskip("torch")
 
 import oracle  # noqa: E402
-from yak_amd import synth  # noqa: E402
+from yak_amd import capi, synth  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -405,3 +405,25 @@ def test_icp_estimate_schedule_edges(gpu_ctx):
         Rh, th, okh = _gn_loop_python(gpu_ctx, dev, {1: (rows, cols)}, ((1, n),), np.eye(3), np.zeros(3))
         assert ok and okh
         assert np.abs(np.array(Rd).reshape(3, 3) - Rh).max() < 1e-5 and np.abs(np.array(td) - th).max() < 1e-5, n
+
+
+def test_fusion_loop_with_the_side_stream_gives_the_same_volume_and_poses(gpu_ctx):
+    """The loop of yak_amd/loop.py prepares frame f + 1 on the context's second stream while frame f is still being
+    integrated and ray cast (yakhip_ctx_side_begin / _end, two ray-distance images in turn): the same voxels and
+    the same poses as everything in one stream, tracking from depth alone and with supplied poses."""
+    from yak_amd.loop import run_kinfu_loop
+
+    scene = [synth.scene_s2(f, noise_mm=1.0) for f in range(0, 24)]
+    for icp in ("device", None):
+        a = run_kinfu_loop(gpu_ctx, 128, 24, icp, scene, overlap=True)
+        b = run_kinfu_loop(gpu_ctx, 128, 24, icp, scene, overlap=False)
+        c = run_kinfu_loop(gpu_ctx, 128, 24, icp, scene, overlap=True, surface_map=False)
+        assert a["volume_checksum"] == b["volume_checksum"] == c["volume_checksum"] != 0
+        assert a["final_pose"] == b["final_pose"] == c["final_pose"]
+    with pytest.raises(capi.YakHipError):
+        gpu_ctx.side_end()                                         # not on the side stream
+    gpu_ctx.side_begin()
+    gpu_ctx.side_begin()                                           # a second begin goes on with the open section
+    gpu_ctx.side_end()
+    with pytest.raises(capi.YakHipError):
+        gpu_ctx.side_end()

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libyakhip.so")
 
 EXPORTS = [
     "yakhip_ctx_create", "yakhip_ctx_destroy", "yakhip_ctx_set_stream", "yakhip_ctx_use_own_stream", "yakhip_ctx_synchronize",
-    "yakhip_device_count", "yakhip_device_name", "yakhip_last_error", "yakhip_ctx_set_option",
+    "yakhip_device_count", "yakhip_device_name", "yakhip_last_error", "yakhip_ctx_set_option", "yakhip_ctx_side_begin", "yakhip_ctx_side_end", "yakhip_ctx_stream",
     "yakhip_ctx_kernel_time", "yakhip_ctx_kernel_times", "yakhip_ctx_brick_stats", "yakhip_selftest_division",
     "yakhip_malloc", "yakhip_malloc_pitch", "yakhip_free", "yakhip_upload", "yakhip_download",
     "yakhip_upload_2d", "yakhip_download_2d", "yakhip_copy", "yakhip_copy_2d",
@@ -98,6 +98,9 @@ def load():
         "yakhip_device_count": [C.POINTER(i)],
         "yakhip_device_name": [i, C.c_char_p, sz],
         "yakhip_ctx_set_option": [vp, C.c_char_p, i],
+        "yakhip_ctx_stream": [vp, C.POINTER(C.c_void_p)],
+        "yakhip_ctx_side_begin": [vp],
+        "yakhip_ctx_side_end": [vp],
         "yakhip_ctx_kernel_time": [vp, C.POINTER(C.c_double), C.POINTER(i)],
         "yakhip_ctx_kernel_times": [vp, fp, fp, i, C.POINTER(i)],
         "yakhip_ctx_brick_stats": [vp, C.POINTER(C.c_ulonglong)],
@@ -242,6 +245,19 @@ class Context:
         _chk(load().yakhip_ctx_synchronize(self._h))
 
     # ---- hot path; pointers are raw device addresses (ints) ----
+    def stream_handle(self):
+        """Raw hipStream_t (int) the context currently enqueues on."""
+        h = C.c_void_p()
+        _chk(load().yakhip_ctx_stream(self._h, C.byref(h)))
+        return h.value or 0
+
+    def side_begin(self):
+        """Calls until side_end() go to the context's second stream (see include/yakhip.h)."""
+        _chk(load().yakhip_ctx_side_begin(self._h))
+
+    def side_end(self):
+        _chk(load().yakhip_ctx_side_end(self._h))
+
     def clear_volume(self, vol):
         _chk(load().yakhip_clear_volume(self._h, C.byref(vol)))
 

@@ -167,6 +167,12 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
     return rc;
   }
   ctx->stream = ctx->own_stream;
+  ctx->side_stream = nullptr;
+  ctx->side_done = nullptr;
+  ctx->main_mark = nullptr;
+  ctx->main_marked = 0;
+  ctx->main_stream = nullptr;
+  ctx->main_stream_saved = 0;
   // set-up for yakhip_integrate_static: this device's address of the library's file-scope scratch array,
   // asked for once per context with the context's device current (each GPU holds its own copy)
   if ((rc = static_scratch_address(&ctx->static_scratch)) != 0)
@@ -213,6 +219,13 @@ int yakhip_ctx_destroy(yakhip_ctx* ctx)
       (void)hipEventDestroy(ev.first);
       (void)hipEventDestroy(ev.second);
     }
+    if (ctx->side_stream)
+    {
+      (void)hipStreamSynchronize(ctx->side_stream);
+      (void)hipStreamDestroy(ctx->side_stream);
+      (void)hipEventDestroy(ctx->side_done);
+      (void)hipEventDestroy(ctx->main_mark);
+    }
     int rc2 = check(hipStreamDestroy(ctx->own_stream), "hipStreamDestroy");
     if (rc == 0)
       rc = rc2;
@@ -225,6 +238,8 @@ int yakhip_ctx_set_stream(yakhip_ctx* ctx, void* hip_stream)
 {
   if (!ctx)
     return fail(YAKHIP_EINVAL, "null context");
+  if (ctx->main_stream_saved)
+    return fail(YAKHIP_EINVAL, "ctx_set_stream: between ctx_side_begin and ctx_side_end");
   ctx->stream = (hipStream_t)hip_stream;
   return 0;
 }
@@ -233,8 +248,55 @@ int yakhip_ctx_use_own_stream(yakhip_ctx* ctx)
 {
   if (!ctx)
     return fail(YAKHIP_EINVAL, "null context");
+  if (ctx->main_stream_saved)
+    return fail(YAKHIP_EINVAL, "ctx_use_own_stream: between ctx_side_begin and ctx_side_end");
   ctx->stream = ctx->own_stream;
   return 0;
+}
+
+int yakhip_ctx_stream(yakhip_ctx* ctx, void** hip_stream)
+{
+  if (!ctx || !hip_stream)
+    return fail(YAKHIP_EINVAL, "ctx_stream: null argument");
+  *hip_stream = (void*)ctx->stream;
+  return 0;
+}
+
+int yakhip_ctx_side_begin(yakhip_ctx* ctx)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (ctx->main_stream_saved)
+    return 0;  // already there: the section goes on until yakhip_ctx_side_end
+  if (!ctx->side_stream)
+  {
+    YAKHIP_TRY(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    YAKHIP_TRY(hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming));
+    YAKHIP_TRY(hipEventCreateWithFlags(&ctx->main_mark, hipEventDisableTiming));
+  }
+  // the side stream may run ahead of the main one by what has been enqueued there since the last side_end, no more
+  if (ctx->main_marked)
+    YAKHIP_TRY(hipStreamWaitEvent(ctx->side_stream, ctx->main_mark, 0));
+  ctx->main_stream = ctx->stream;
+  ctx->main_stream_saved = 1;
+  ctx->stream = ctx->side_stream;
+  return 0;
+}
+
+int yakhip_ctx_side_end(yakhip_ctx* ctx)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if (!ctx->main_stream_saved)
+    return fail(YAKHIP_EINVAL, "ctx_side_end: not on the side stream");
+  ctx->stream = ctx->main_stream;
+  ctx->main_stream_saved = 0;
+  YAKHIP_TRY(hipEventRecord(ctx->side_done, ctx->side_stream));
+  YAKHIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
+  ctx->main_marked = 1;
+  return check(hipEventRecord(ctx->main_mark, ctx->stream), "hipEventRecord");
 }
 
 int yakhip_ctx_synchronize(yakhip_ctx* ctx)

@@ -13,7 +13,10 @@ struct yakhip_ctx
 {
   int device;
   hipStream_t own_stream;
-  hipStream_t stream;  // own_stream or a borrowed one
+  hipStream_t stream;  // own_stream or a borrowed one (between ctx_side_begin / _end: side_stream)
+  hipStream_t side_stream, main_stream;  // yakhip_ctx_side_begin: a second stream, created on first use; the stream to go back to
+  hipEvent_t side_done, main_mark;  // end of the side work; the main stream's position at the last side_end
+  int main_stream_saved, main_marked;
   int z_chunk;         // 0 = auto
   int nontemporal;     // volume stream bypasses cache retention
   int force_vx;        // 0 = widest the layout allows; 1/2/4 caps the voxels per lane

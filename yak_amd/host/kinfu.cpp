@@ -4,6 +4,7 @@
 
 #include <yakhip.h>
 
+#include <cstdlib>
 #include <iostream>
 #include <stdexcept>
 
@@ -65,6 +66,14 @@ KinFu::KinFu(const KinFuParams& params) : frame_counter_(0), params_(params)
   icp_->setAngleThreshold(params_.icp_angle_thres);
   icp_->setIterationsNum(params_.icp_iter_num);
 
+  // Frame f + 1 is prepared on the context's second stream while frame f is still being integrated and ray cast,
+  // and nothing waits at the end of a frame (the reference synchronises the device three times per frame:
+  // kinfu.cpp:188, tsdf_volume.cu:139, kinfu.cpp:307); every later call is ordered behind the work in the stream
+  // anyway.  YAK_HIP_OVERLAP=0 restores the waits.
+  const char* env = std::getenv("YAK_HIP_OVERLAP");
+  overlap_ = !(env && env[0] == '0');
+  volume_->setBlockingIntegrate(!overlap_);
+
   allocate_buffers();
   resetVolume();
   poses_.reserve(30000);
@@ -83,6 +92,7 @@ void KinFu::allocate_buffers()  // kinfu.cpp:94-129 (the USE_DEPTH-only depth py
   const int LEVELS = cuda::ProjectiveICP::MAX_PYRAMID_LEVELS;
   int cols = params_.cols, rows = params_.rows;
   dists_.create(rows, cols);
+  dists_alt_.create(rows, cols);
   curr_.depth_pyr.resize(LEVELS);
   curr_.normals_pyr.resize(LEVELS);
   curr_.points_pyr.resize(LEVELS);
@@ -181,13 +191,21 @@ void KinFu::downloadModelMaps(void* points_out, void* normals_out) const
 }
 
 // kinfu.cpp:162-309
+void KinFu::beginFrame()
+{
+  if (overlap_ && yakhip_ctx_side_begin(cuda::context()) != 0)
+    cuda::error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_ctx_side_begin");
+}
+
 bool KinFu::operator()(const Affine3f& inputCameraMotion, const Affine3f& currentCameraPose,
                        const Affine3f& previousCameraPose, const cuda::Depth& depth, const cuda::Image& /*image*/)
 {
   const KinFuParams& p = params_;
   const int LEVELS = icp_->getUsedLevelsNum();
 
-  cuda::computeDists(depth, dists_, p.intr);  // :171
+  cuda::Dists& dists = (frame_counter_ & 1) ? dists_alt_ : dists_;
+  beginFrame();  // (goes on with the section if the caller opened it for the upload)
+  cuda::computeDists(depth, dists, p.intr);  // :171
   // :172-186 feed ICP only; the reference runs them on every frame regardless of use_icp, and so
   // does this loop (prev_ must hold frame 0's maps when tracking starts on frame 1)
   cuda::depthBilateralFilter(depth, curr_.depth_pyr[0], p.bilateral_kernel_size, p.bilateral_sigma_spatial,
@@ -198,11 +216,17 @@ bool KinFu::operator()(const Affine3f& inputCameraMotion, const Affine3f& curren
     cuda::depthBuildPyramid(curr_.depth_pyr[i - 1], curr_.depth_pyr[i], p.bilateral_sigma_depth);
   for (int i = 0; i < LEVELS; ++i)
     cuda::computePointNormals(p.intr(i), curr_.depth_pyr[i], curr_.points_pyr[i], curr_.normals_pyr[i]);
-  cuda::waitAllDefaultStream();  // :188
+  if (overlap_)
+  {
+    if (yakhip_ctx_side_end(cuda::context()) != 0)
+      cuda::error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_ctx_side_end");
+  }
+  else
+    cuda::waitAllDefaultStream();  // :188
 
   if (frame_counter_ == 0)  // :191-201 -- integrates at the stored pose, reports false
   {
-    volume_->integrate(dists_, poses_.back(), p.intr);
+    volume_->integrate(dists, poses_.back(), p.intr);
     curr_.points_pyr.swap(prev_.points_pyr);
     curr_.normals_pyr.swap(prev_.normals_pyr);
     return ++frame_counter_, false;
@@ -242,14 +266,15 @@ bool KinFu::operator()(const Affine3f& inputCameraMotion, const Affine3f& curren
   const float rnorm = (float)yak::compat::norm(cameraMotion.rvec());
   const float tnorm = (float)yak::compat::norm(cameraMotion.translation());
   if ((rnorm + tnorm) / 2 >= p.tsdf_min_camera_movement)
-    volume_->integrate(dists_, poses_.back(), p.intr);
+    volume_->integrate(dists, poses_.back(), p.intr);
 
   // :294-306 -- the model as seen from the new pose becomes the next frame's ICP target
   volume_->raycast(poses_.back(), p.intr, prev_.points_pyr[0], prev_.normals_pyr[0]);
   for (int i = 1; i < LEVELS; ++i)
     cuda::resizePointsNormals(prev_.points_pyr[i - 1], prev_.normals_pyr[i - 1], prev_.points_pyr[i],
                               prev_.normals_pyr[i]);
-  cuda::waitAllDefaultStream();
+  if (!overlap_ || cuda::currentShard().world > 1)
+    cuda::waitAllDefaultStream();
   if (volume_->raycastOverflowed())  // sharded volume only: more pixels to settle than the composite's list holds
   {
     YAK_SET_OPTION("composite_capacity", p.rows * p.cols);

@@ -198,6 +198,7 @@ bool ShardedKinFu::operator()(const Affine3f& inputCameraMotion, const Affine3f&
   std::vector<int> result(ranks_.size(), 0);
   forEachRank([&](int rank, KinFu& kf) {
     Rank* r = ranks_[(size_t)rank];
+    kf.beginFrame();
     r->depth.upload(depth_host, step, rows, cols);
     result[(size_t)rank] = kf(inputCameraMotion, currentCameraPose, previousCameraPose, r->depth) ? 1 : 0;
   });

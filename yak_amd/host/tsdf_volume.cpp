@@ -97,6 +97,7 @@ TsdfVolume::Entry::half TsdfVolume::Entry::float2half(float value)
 TsdfVolume::TsdfVolume(const Vec3i& dims)
   : held_z0_(0)
   , held_z1_(0)
+  , blocking_integrate_(true)
   , map_stale_(false)
   , data_()
   , trunc_dist_(0.03f)
@@ -257,6 +258,7 @@ void TsdfVolume::swap(CudaData& data)
   map_stale_ = true;
 }
 void TsdfVolume::applyAffine(const Affine3f& affine) { pose_ = affine * pose_; }
+void TsdfVolume::setBlockingIntegrate(bool blocking) { blocking_integrate_ = blocking; }
 
 void TsdfVolume::clear()  // :80-87
 {
@@ -281,7 +283,8 @@ void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_motion_tfo
   // a rank integrates every layer it holds: its own and, redundantly, the halo (nothing is exchanged)
   const yakhip_volume v = view();
   YAK_CHECK(yakhip_integrate(context(), &v, dists.ptr(), dists.step(), dists.rows(), dists.cols(), Rf, tf, in));
-  YAK_CHECK(yakhip_ctx_synchronize(context()));
+  if (blocking_integrate_)
+    YAK_CHECK(yakhip_ctx_synchronize(context()));
 }
 
 namespace

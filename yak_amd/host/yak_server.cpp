@@ -106,6 +106,9 @@ bool FusionServer::fuse(const cv::Mat& depth_data, const Eigen::Affine3f& world_
                                   depth_data.step, depth_data.rows, depth_data.cols);
   else
   {
+    // the upload opens the side-stream section that KinFu::operator() continues (pre-processing) and ends: the copy
+    // does not queue up behind the integrate and ray cast of the frame before
+    kinfu_->beginFrame();
     depthDevice_.upload(depth_data.data, depth_data.step, depth_data.rows, depth_data.cols);
     result = kinfu_->operator()(to_kf(motion), to_kf(current_camera_in_volume), to_kf(last_camera_pose_), depthDevice_);
   }

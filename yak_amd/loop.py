@@ -19,10 +19,13 @@ def rodrigues(r):
     return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * K @ K
 
 
-def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None, on_system=None, surface_map=True):
+def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None, on_system=None, surface_map=True, overlap=True):
     """icp: "device" (yakhip_icp_estimate, one wait per frame), "host" (one blocking linearisation at a time,
     numpy solve) or None (true poses supplied).  scene: the frames, if the caller made them already (a list of
-    synth.scene_s2(f, noise_mm=1.0) for f in range(frames)).  Returns a dict with frames/s and per-stage stream times."""
+    synth.scene_s2(f, noise_mm=1.0) for f in range(frames)).  overlap: the frame's pre-processing goes to the context's
+    second stream (yakhip_ctx_side_begin), where it runs while the integrate and ray cast of the frame before are still
+    in flight; the host never waits for the device except for the ICP result.  Returns a dict with frames/s and
+    per-stage stream times."""
     import torch
 
     from . import capi, synth
@@ -38,7 +41,7 @@ def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None, on_system=No
     i16 = lambda r, c: torch.empty((r, c), dtype=torch.int16, device="cuda")        # noqa: E731
     f4 = lambda r, c: torch.empty((r, c, 4), dtype=torch.float32, device="cuda")    # noqa: E731
     LEVELS, iters = 3, (10, 5, 4)  # iterations on levels 0, 1, 2 (iters_[level_index], projective_icp.cpp:206)
-    dists = i16(rows, cols)
+    dists2 = [i16(rows, cols), i16(rows, cols)]  # two: frame f + 1 is prepared while frame f is still being integrated
     cur_d = [i16(rows >> l, cols >> l) for l in range(LEVELS)]
     cur_p = [f4(rows >> l, cols >> l) for l in range(LEVELS)]
     cur_n = [f4(rows >> l, cols >> l) for l in range(LEVELS)]
@@ -68,10 +71,15 @@ def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None, on_system=No
     t_start = time.perf_counter()
     worst = 0.0
     icp_ms = []
+    events = []
     for f in range(n_frames):
         e = [ev() for _ in range(5)]
-        e[0].record()
+        events.append(e)
         d = dev_depth[f]
+        dists = dists2[f & 1]
+        if overlap:
+            ctx.side_begin()
+        e[0].record(torch.cuda.ExternalStream(ctx.stream_handle()) if overlap else None)
         ctx.compute_dists(d.data_ptr(), cols * 2, dists.data_ptr(), cols * 2, rows, cols, intr)
         ctx.bilateral_filter(d.data_ptr(), cols * 2, cur_d[0].data_ptr(), cols * 2, rows, cols, 7, 4.5, 0.04)
         for l in range(1, LEVELS):
@@ -81,6 +89,11 @@ def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None, on_system=No
             li = tuple(np.float32(v) / np.float32(1 << l) for v in intr)
             ctx.compute_points_normals(li, cur_d[l].data_ptr(), (cols >> l) * 2, rows >> l, cols >> l, cur_p[l].data_ptr(),
                                        (cols >> l) * 16, cur_n[l].data_ptr(), (cols >> l) * 16)
+        if overlap:
+            pre_end = ev()
+            pre_end.record(torch.cuda.ExternalStream(ctx.stream_handle()))
+            e.append(pre_end)
+            ctx.side_end()
         e[1].record()
         if f > 0 and icp is not None:
             if icp == "host":
@@ -135,15 +148,18 @@ def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None, on_system=No
                                           (cols >> (l - 1)) * 16, rows >> (l - 1), cols >> (l - 1), prv_p[l].data_ptr(),
                                           (cols >> l) * 16, prv_n[l].data_ptr(), (cols >> l) * 16)
         e[4].record()
-        torch.cuda.synchronize()
-        for name, a, b_ in (("preprocess", 0, 1), ("icp", 1, 2), ("integrate", 2, 3), ("raycast", 3, 4)):
-            stage[name] += e[a].elapsed_time(e[b_])
-        icp_ms.append(e[1].elapsed_time(e[2]))
         tR, tt = c2v(scene[f][1], scene[f][2])
         worst = max(worst, float(np.linalg.norm(pose_t - tt)))
+    torch.cuda.synchronize()
     wall = time.perf_counter() - t_start
+    for e in events:
+        for name, a, b_ in (("preprocess", 0, 5 if overlap else 1), ("icp", 1, 2), ("integrate", 2, 3), ("raycast", 3, 4)):
+            stage[name] += e[a].elapsed_time(e[b_])
+        icp_ms.append(e[1].elapsed_time(e[2]))
     if gc_was_enabled:
         gc.enable()
+    checksum = int((vol.to(torch.int64) * (torch.arange(vol.numel(), device="cuda", dtype=torch.int64) % 65521 + 1)).sum().item())
     return {"n": n, "frames": n_frames, "icp": icp, "frames_per_s": n_frames / wall, "wall_s": wall,
+            "final_pose": (np.float64(pose_R).tolist(), np.float64(pose_t).tolist()), "volume_checksum": checksum,
             "worst_position_error_mm": worst * 1e3, "stage_ms": {k: v / n_frames for k, v in stage.items()},
             "icp_ms_per_frame": icp_ms}
