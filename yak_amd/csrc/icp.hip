@@ -17,6 +17,9 @@ namespace yakhip
 {
 namespace
 {
+#ifndef YAK_ICP_NB
+#define YAK_ICP_NB 1
+#endif
 constexpr int kValues = 33;        // 27 products + accepted + rejected{40,80,120,160,200}
 constexpr int kPixelsPerLane = 4;  // a workgroup covers 1024 consecutive pixels
 
@@ -454,15 +457,21 @@ __device__ __forceinline__ float block_value(const float (*lds)[kValues], int k)
   return ((lds[0][k] + lds[1][k]) + lds[2][k]) + lds[3][k];
 }
 
-__global__ __launch_bounds__(256) void icp_accumulate_kernel(const IcpParams p, float* partial, int n_blocks)
+// NB blocks of 256 lanes per workgroup; the block sums and their order are the same for every NB.  Measured in the
+// fusion loop, same box: NB = 1 2 340-2 370 frames/s, NB = 2 (half as many workgroups of 512 lanes) 2 280-2 320.
+template <int NB>
+__global__ __launch_bounds__(256 * NB) void icp_accumulate_kernel(const IcpParams p, float* partial, int n_blocks)
 {
   float acc[kValues];
 #pragma unroll
   for (int k = 0; k < kValues; ++k)
     acc[k] = 0.f;
 
+  const int tid = (int)threadIdx.x & 255, sub = (int)threadIdx.x >> 8;
+  const int block = (int)blockIdx.x * NB + sub;
+  const bool exists = block < n_blocks;
   CurrentMaps cur;
-  load_current(p, (int)blockIdx.x, (int)threadIdx.x, cur);
+  load_current(p, exists ? block : 0, tid, cur);
   float R[9], t[3];
   if (p.state)
   {
@@ -473,7 +482,7 @@ __global__ __launch_bounds__(256) void icp_accumulate_kernel(const IcpParams p, 
       // not gated by the status: the partial loads then leave together with the state's scalar loads (one
       // trip to the fabric instead of two); after a stop they read stale scratch, which nobody uses
       __shared__ float prev_sums[kValues];
-      reduce_partials<4>(p.prev_partial, p.prev_blocks, prev_sums);
+      reduce_partials<4 * NB>(p.prev_partial, p.prev_blocks, prev_sums);
       __syncthreads();
       if (st.status == 0)
         solve_update(prev_sums, st);
@@ -499,16 +508,14 @@ __global__ __launch_bounds__(256) void icp_accumulate_kernel(const IcpParams p, 
       t[i] = p.t[i];
   }
 
-  accumulate_pixels(p, R, t, cur, acc);
+  if (exists)
+    accumulate_pixels(p, R, t, cur, acc);
 
-  __shared__ float lds[4][kValues];
-  block_sums_to_lds(acc, lds, (int)threadIdx.x);
+  __shared__ float lds[NB][4][kValues];
+  block_sums_to_lds(acc, lds[sub], tid);
   __syncthreads();
-  if (threadIdx.x < kValues)
-  {
-    const int k = (int)threadIdx.x;
-    partial[(size_t)k * n_blocks + blockIdx.x] = block_value(lds, k);
-  }
+  if (tid < kValues && exists)
+    partial[(size_t)tid * n_blocks + block] = block_value(lds[sub], tid);
 }
 
 // One wave per value: lane j adds partials j, j + 64, ... in order, then the butterfly.
@@ -590,7 +597,7 @@ int launch_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], c
     return rc;
   float* partial = (float*)ctx->icp_scratch;
   float* result = partial + (size_t)n_blocks * kValues;
-  hipLaunchKernelGGL(icp_accumulate_kernel, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, p, partial, n_blocks);
+  hipLaunchKernelGGL(icp_accumulate_kernel<1>, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, p, partial, n_blocks);
   YAKHIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(icp_final_kernel, dim3(kValues), dim3(64), 0, ctx->stream, partial, n_blocks,
                      sums_dev ? sums_dev : result);
@@ -707,7 +714,7 @@ int launch_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], con
         p.state_out = &slots[j];
         p.prev_partial = j == 0 ? nullptr : partial[(j - 1) & 1];
         p.prev_blocks = prev_blocks;
-        hipLaunchKernelGGL(icp_accumulate_kernel, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, p, partial[j & 1],
+        hipLaunchKernelGGL(icp_accumulate_kernel<YAK_ICP_NB>, dim3((unsigned)((n_blocks + YAK_ICP_NB - 1) / YAK_ICP_NB)), dim3(256 * YAK_ICP_NB), 0, ctx->stream, p, partial[j & 1],
                            n_blocks);
         prev_blocks = n_blocks;
       }
@@ -833,7 +840,7 @@ int launch_icp_estimate_sharded(yakhip_ctx* ctx, yakhip_comm* comm, const float 
         p.state_out = &slots[j];
         p.prev_partial = j == 0 ? nullptr : sums[(j - 1) & 1];
         p.prev_blocks = 1;
-        hipLaunchKernelGGL(icp_accumulate_kernel, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, p, partial, n_blocks);
+        hipLaunchKernelGGL(icp_accumulate_kernel<1>, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, p, partial, n_blocks);
         hipLaunchKernelGGL(icp_final_kernel, dim3(kValues), dim3(64), 0, ctx->stream, partial, n_blocks, sums[j & 1]);
         YAKHIP_TRY(hipGetLastError());
         if ((rc = comm_allreduce(ctx, comm, sums[j & 1], kValues, YAKHIP_SUM_F32)) != 0)
