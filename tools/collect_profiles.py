@@ -18,7 +18,7 @@ dst = os.path.join(ROOT, "profiles")
 
 
 def one(pattern):
-    return glob.glob(os.path.join(src, pattern), recursive=True)[0]
+    return max(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)  # (gpurun merges: older runs' files stay)
 
 
 shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
