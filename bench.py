@@ -172,11 +172,14 @@ def next_rows(ctx, torch, capi, synth, with_cpu):
     out["icp_accumulate_level0_ms_blocking"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
 
     # marching cubes: count pass + scan + emit pass; HBM roofline on 2 reads of the volume + the triangles
-    ntri = ctx.marching_cubes(desc, 2, vs[0])
+    ntri = ctx.marching_cubes(plain, 2, vs[0])
     tri = torch.empty((max(ntri, 1), 9), dtype=torch.float32, device="cuda")
-    ms = timed(lambda: ctx.marching_cubes(desc, 2, vs[0], tri.data_ptr(), ntri), 5)
-    mc_bytes = 4 * n ** 3 + 36 * ntri  # the least any extraction moves: one read of the volume + the triangles
-    out["marching_cubes"] = {"ms_both_passes": round(ms, 4), "triangles": ntri, "algorithmic_bytes": mc_bytes,
+    ms = timed(lambda: ctx.marching_cubes(plain, 2, vs[0], tri.data_ptr(), ntri), 5)
+    # with the volume's surface map the count pass reads only near marked bricks (the same triangles)
+    ms_map = timed(lambda: ctx.marching_cubes(desc, 2, vs[0], tri.data_ptr(), ntri), 5)
+    mc_bytes = 4 * n ** 3 + 36 * ntri  # the least an extraction without prior knowledge moves: one read of the volume + the triangles
+    out["marching_cubes"] = {"ms_both_passes": round(ms, 4), "ms_both_passes_with_surface_map": round(ms_map, 4),
+                             "triangles": ntri, "algorithmic_bytes": mc_bytes,
                              "achieved_GBps": round(mc_bytes / (ms * 1e-3) / 1e9, 1),
                              "frac_of_hbm_peak": round(mc_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                              "Gvox_per_s": round(n ** 3 / (ms * 1e-3) / 1e9, 1)}
@@ -342,7 +345,9 @@ def run_c5(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, e
     if args.no_brick:
         ctx.set_option("brick_test", 0)
     vol = torch.empty(layers * n * n, dtype=torch.int32, device="cuda")
-    held = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT, z0, z1h)
+    held_plain = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT, z0, z1h)
+    smap = torch.zeros(capi.surface_map_bytes(held_plain) // 4, dtype=torch.int32, device="cuda")
+    held = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT, z0, z1h, surface_map=smap.data_ptr())
     frames, keep = [], []
     for f in C5_CAMERAS:
         depth, R, t = synth.scene_s2(f)
@@ -393,15 +398,20 @@ def run_c5(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, e
     for _ in range(mc_reps):
         ctx.marching_cubes(held, 2, vs[0], tri.data_ptr(), ntri)
     mc_ms = (time.perf_counter() - t0) / mc_reps * 1e3
+    t0 = time.perf_counter()
+    for _ in range(mc_reps):
+        ctx.marching_cubes(held_plain, 2, vs[0], tri.data_ptr(), ntri)
+    mc_plain_ms = (time.perf_counter() - t0) / mc_reps * 1e3
     del tri
 
-    totals = torch.tensor([elapsed, kernel_ms, mc_ms, float(updates), float(touched), float(ntri)], dtype=torch.float64,
+    # (mc_ms: with the slab's surface map, kept by the sweeps above; mc_plain_ms: without)
+    totals = torch.tensor([elapsed, kernel_ms, mc_ms, float(updates), float(touched), float(ntri), mc_plain_ms], dtype=torch.float64,
                           device="cpu" if share_gpu else "cuda")
     if dist is not None:
         mx, sm = totals.clone(), totals.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed, kernel_ms, mc_ms = float(mx[0]), float(mx[1]), float(mx[2])
+        elapsed, kernel_ms, mc_ms, mc_plain_ms = float(mx[0]), float(mx[1]), float(mx[2]), float(mx[6])
         updates_total, touched_total, ntri_total = int(sm[3]), int(sm[4]), int(sm[5])
     else:
         updates_total, touched_total, ntri_total = updates, touched, ntri
@@ -439,13 +449,16 @@ def run_c5(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, e
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "rank 0's slab; bound by the per-voxel path of the bricks that hold surface, not by HBM "
                                  "(only touched voxels count as algorithmic bytes)"},
-            "marching_cubes": {"ms_per_extraction_slowest_rank": round(mc_ms, 4), "triangles": ntri_total,
+            "marching_cubes": {"ms_per_extraction_slowest_rank": round(mc_ms, 4),
+                               "ms_per_extraction_without_surface_map": round(mc_plain_ms, 4), "triangles": ntri_total,
                                "Gvox_per_s_per_gpu": round(visited / (mc_ms * 1e-3) / 1e9, 1),
-                               "algorithmic_GBps_rank0": round(mc_bytes / (mc_ms * 1e-3) / 1e9, 1),
-                               "frac_of_hbm_peak_rank0": round(mc_bytes / (mc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                               "algorithmic_GBps_rank0": round(mc_bytes / (mc_plain_ms * 1e-3) / 1e9, 1),
+                               "frac_of_hbm_peak_rank0": round(mc_bytes / (mc_plain_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                "how": "count pass, scan, emit pass over the slab + 1 overlap layer; wall time of the "
-                                      "blocking call (the host reads the count back); algorithmic bytes = one read of the "
-                                      "slab + 36 B per triangle (the emit pass re-reads only tiles that hold surface)"},
+                                      "blocking call (the host reads the count back).  With the slab's surface map (kept by "
+                                      "the integrate sweeps) the count pass reads only near marked bricks; the bytes figure "
+                                      "is for the extraction WITHOUT it: one read of the slab + 36 B per triangle (the emit "
+                                      "pass re-reads only tiles that hold surface)"},
         }
         if emulate:
             out["config"]["emulated_rank"] = "%d of %d (this GPU's slab only: value is per GPU)" % (rank, world)

@@ -74,7 +74,7 @@ typedef struct yakhip_volume
  *   yakhip_integrate / _static / _batch   set the bits of the bricks in which a negative measurement was folded
  *                                         into a voxel (nothing else can make a voxel negative);
  *   yakhip_clear_volume                   clears the map with the voxels;
- *   yakhip_raycast_* (and _slab/_sharded) consult it;
+ *   yakhip_raycast_* (and _slab/_sharded) and yakhip_marching_cubes[_layers] consult it;
  *   yakhip_surface_map_rebuild            recomputes it from the voxels.
  * The map belongs to one (data, z0, z1): pass the same three with it every time.  Whoever writes voxels by other
  * means (an upload, a copy, a kernel of his own) calls yakhip_surface_map_rebuild before the next ray cast, or
@@ -457,6 +457,14 @@ int yakhip_icp_estimate_sharded(yakhip_ctx* ctx, yakhip_comm* comm, const float 
  * VTK's vtkCleanPolyData in the reference, :204-216; the host layer does it). */
 int yakhip_marching_cubes(yakhip_ctx* ctx, const yakhip_volume* vol, int min_weight, double scale, void* triangles_dev,
                           unsigned long long capacity_triangles, unsigned long long* n_triangles_host);
+/* The same over the layers [z_first, z_last) of the slab `vol` (z0 <= z_first < z_last <= z1): the cubes
+ * z_first .. z_last - 2.  For a rank that holds more layers than it meshes (its ray-cast halo): the slab's surface
+ * map, which belongs to the whole slab, still applies.  With a surface map (either call) the count pass reads only
+ * where a marked brick is near -- a cube has triangles only if one of its corners is negative --; the triangles are
+ * the same set in the same order. */
+int yakhip_marching_cubes_layers(yakhip_ctx* ctx, const yakhip_volume* vol, int z_first, int z_last, int min_weight,
+                                 double scale, void* triangles_dev, unsigned long long capacity_triangles,
+                                 unsigned long long* n_triangles_host);
 
 /* The exact part of MarchingCubesParameters::clean (yak/src/mc/marching_cubes.cpp:204-216: vtkCleanPolyData,
  * point merging on): corners of the triangle soup with the same three bit patterns become one vertex.

@@ -299,6 +299,39 @@ def test_raycast_512_with_the_map_on_a_volume_fused_on_the_gpu(gpu_ctx):
         assert same_bits(raycast(gpu_ctx, s.desc, R, t, R_v2c, synth.INTR, rows, cols), plain)
 
 
+def test_marching_cubes_with_the_map_gives_the_same_triangles(gpu_ctx):
+    """The count pass leaves out what no marked brick is near; the triangle list is the same, entry for entry --
+    whole slab, a slab that starts inside the volume, and a layer range of a slab (yakhip_marching_cubes_layers)."""
+    for dims, z0, z1 in [((128, 128, 128), 0, None), ((72, 40, 100), 0, None), ((96, 96, 160), 37, 121)]:
+        _, vs, tr = synth.volume_geometry(dims)
+        s = Slab(dims, vs, tr, z0, z1)
+        gpu_ctx.clear_volume(s.desc)
+        rows, cols = synth.ROWS, synth.COLS
+        for d, R, t in orbit_frames([0, 60, 120, 180, 240]):
+            dd = dev_u16_image(d)
+            gpu_ctx.integrate(s.desc, dd.data_ptr(), cols * 2, rows, cols, R.reshape(-1), t, synth.INTR)
+
+        def mesh(call, *args):
+            n = call(*args, 2, vs[0])
+            tri = torch.full((max(n, 1), 9), 7.0, dtype=torch.float32, device="cuda")
+            assert call(*args, 2, vs[0], tri.data_ptr(), n) == n
+            return tri.cpu().numpy()[:n]
+
+        plain = mesh(gpu_ctx.marching_cubes, s.plain)
+        assert len(plain) > 500
+        assert np.array_equal(mesh(gpu_ctx.marching_cubes, s.desc).view(np.uint32), plain.view(np.uint32))
+        # a range of the slab's layers: what a separate slab over those layers gives
+        a, b = s.z0 + 5, s.z1 - 9
+        plane = dims[0] * dims[1]
+        sub = capi.volume_desc(s.vol.data_ptr() + 4 * plane * (a - s.z0), dims, vs, tr, synth.MAX_WEIGHT, a, b)
+        want = mesh(gpu_ctx.marching_cubes, sub)
+        assert len(want) > 300
+        for desc in (s.desc, s.plain):
+            assert np.array_equal(mesh(gpu_ctx.marching_cubes_layers, desc, a, b).view(np.uint32), want.view(np.uint32))
+    with pytest.raises(capi.YakHipError):
+        gpu_ctx.marching_cubes_layers(s.desc, s.z0 - 1, s.z1, 2, 1.0)
+
+
 def test_surface_map_arguments(gpu_ctx):
     dims, vs, tr = synth.volume_geometry((40, 33, 50))
     s = Slab(dims, vs, tr, 3, 47)

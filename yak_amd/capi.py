@@ -21,7 +21,7 @@ EXPORTS = [
     "yakhip_raycast_points", "yakhip_raycast_depth", "yakhip_raycast_slab", "yakhip_raycast_resolve", "yakhip_raycast_halo",
     "yakhip_bilateral_filter", "yakhip_truncate_depth", "yakhip_depth_pyramid", "yakhip_compute_points_normals",
     "yakhip_resize_points_normals", "yakhip_icp_accumulate", "yakhip_icp_accumulate_rows", "yakhip_icp_estimate",
-    "yakhip_marching_cubes", "yakhip_weld_vertices", "yakhip_extract_cloud", "yakhip_extract_normals",
+    "yakhip_marching_cubes", "yakhip_marching_cubes_layers", "yakhip_weld_vertices", "yakhip_extract_cloud", "yakhip_extract_normals",
     "yakhip_render_image_points", "yakhip_render_image_depth", "yakhip_render_tangent_colors",
     "yakhip_comm_unique_id", "yakhip_comm_create_rccl", "yakhip_comm_create_local", "yakhip_comm_create_custom",
     "yakhip_comm_destroy", "yakhip_comm_info", "yakhip_comm_allreduce", "yakhip_comm_status",
@@ -135,6 +135,7 @@ def load():
         "yakhip_resize_points_normals": [vp, vp, sz, vp, sz, i, i, vp, sz, vp, sz],
         "yakhip_icp_estimate": [vp, fp, fp, fp, C.c_float, C.c_float, C.POINTER(IcpLevel), i, fp, fp, C.POINTER(i)],
         "yakhip_marching_cubes": [vp, volp, i, C.c_double, vp, C.c_ulonglong, C.POINTER(C.c_ulonglong)],
+        "yakhip_marching_cubes_layers": [vp, volp, i, i, i, C.c_double, vp, C.c_ulonglong, C.POINTER(C.c_ulonglong)],
         "yakhip_weld_vertices": [vp, vp, C.c_ulonglong, vp, vp, C.POINTER(C.c_ulonglong)],
         "yakhip_extract_cloud": [vp, volp, fp, fp, vp, C.c_ulonglong, C.POINTER(C.c_ulonglong)],
         "yakhip_extract_normals": [vp, volp, vp, C.c_ulonglong, fp, fp, fp, C.c_float, vp],
@@ -401,6 +402,13 @@ class Context:
         n = C.c_ulonglong(0)
         _chk(load().yakhip_marching_cubes(self._h, C.byref(vol), int(min_weight), float(scale),
                                           C.c_void_p(triangles_ptr or 0), int(capacity), C.byref(n)))
+        return n.value
+
+    def marching_cubes_layers(self, vol, z_first, z_last, min_weight, scale, triangles_ptr=0, capacity=0):
+        """marching_cubes over the layers [z_first, z_last) of the slab `vol` (whose surface map still applies)."""
+        n = C.c_ulonglong(0)
+        _chk(load().yakhip_marching_cubes_layers(self._h, C.byref(vol), int(z_first), int(z_last), int(min_weight), float(scale),
+                                                 C.c_void_p(triangles_ptr or 0), int(capacity), C.byref(n)))
         return n.value
 
     def weld_vertices(self, triangles_ptr, n_triangles, vertices_ptr, index_ptr):

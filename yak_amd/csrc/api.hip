@@ -1565,7 +1565,30 @@ int yakhip_marching_cubes(yakhip_ctx* ctx, const yakhip_volume* vol, int min_wei
     return fail(YAKHIP_EALIGN, "marching_cubes: triangle buffer must be 4-byte aligned");
   return launch_marching_cubes(ctx, (const uint32_t*)vol->data, vol->dims[0], vol->dims[1], vol->z0, vol->z1 - vol->z0,
                                min_weight, scale, (float*)triangles_dev, triangles_dev ? capacity_triangles : 0,
-                               n_triangles_host);
+                               n_triangles_host, (const uint32_t*)vol->surface_map, 0);
+}
+
+int yakhip_marching_cubes_layers(yakhip_ctx* ctx, const yakhip_volume* vol, int z_first, int z_last, int min_weight,
+                                 double scale, void* triangles_dev, unsigned long long capacity_triangles,
+                                 unsigned long long* n_triangles_host)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_volume(vol)) != 0)
+    return rc;
+  if (!n_triangles_host)
+    return fail(YAKHIP_EINVAL, "marching_cubes_layers: null count pointer");
+  if (triangles_dev && (uintptr_t)triangles_dev % 4 != 0)
+    return fail(YAKHIP_EALIGN, "marching_cubes_layers: triangle buffer must be 4-byte aligned");
+  if (!(vol->z0 <= z_first && z_first < z_last && z_last <= vol->z1))
+    return fail(YAKHIP_EINVAL, "marching_cubes_layers: layers [%d, %d) are not part of the slab [%d, %d)", z_first, z_last,
+                vol->z0, vol->z1);
+  const size_t plane = (size_t)vol->dims[0] * (size_t)vol->dims[1];
+  return launch_marching_cubes(ctx, (const uint32_t*)vol->data + plane * (size_t)(z_first - vol->z0), vol->dims[0],
+                               vol->dims[1], z_first, z_last - z_first, min_weight, scale, (float*)triangles_dev,
+                               triangles_dev ? capacity_triangles : 0, n_triangles_host, (const uint32_t*)vol->surface_map,
+                               z_first - vol->z0);
 }
 
 int yakhip_weld_vertices(yakhip_ctx* ctx, const void* triangles_dev, unsigned long long n_triangles, void* vertices_dev,

@@ -45,6 +45,10 @@ struct McParams
   int z_sub, nzs;       // cube layers per tile (what is counted, scanned and emitted as a unit); divides z_chunk
   int min_weight;
   double scale;
+  // surface map of the slab `vol` is part of (yakhip_volume.surface_map), or nullptr: bit (bx + map_x * (by + map_y * bz))
+  // set = the brick of 16^3 voxels may hold a negative voxel; vol's first layer is layer map_z0 of that slab
+  const uint32_t* map;
+  int map_x, map_y, map_z0;
 };
 
 // corner c of the cube sits at (x + dx, y + dy, z + dz): marching_cubes.cpp:33-37
@@ -105,6 +109,30 @@ __global__ __launch_bounds__(256) void mc_kernel(const McParams p, uint32_t* cou
   const int walk = EMIT ? p.z_sub : p.z_chunk;
   const size_t tile_stride = (size_t)p.ny * p.nx;
   size_t tile = ((size_t)zc * (size_t)(walk / p.z_sub) * p.ny + yt) * p.nx + xt;  // first tile of this wave
+  if (!EMIT && p.map)
+  {
+    // A cube has triangles only if one of its corners is negative (cases 0 and 255 have none), and a brick whose
+    // bit is clear holds no negative voxel: if none of the <= 5 x 2 x 3 bricks that this wave's voxels lie in is
+    // marked, its tiles are empty and nothing is read.
+    const int vx0 = xt * kRun, vx1 = min(vx0 + kRun, p.X - 1), vy0 = yt * kRows, vy1 = min(vy0 + kRows, p.Y - 1);
+    const int vz0 = zc * walk, vz1 = min(vz0 + walk, p.cube_layers);  // voxel layers vz0 .. vz1 (cube layer z uses z and z + 1)
+    const int bx0 = vx0 >> 4, nbx = (vx1 >> 4) - bx0 + 1, by0 = vy0 >> 4, nby = (vy1 >> 4) - by0 + 1;
+    const int bz0 = (vz0 + p.map_z0) >> 4, nbz = ((vz1 + p.map_z0) >> 4) - bz0 + 1;
+    bool marked = false;
+    for (int i = lane; i < nbx * nby * nbz; i += 64)
+    {
+      const int ix = i % nbx, iy = (i / nbx) % nby, iz = i / (nbx * nby);
+      const uint32_t b = (uint32_t)(bx0 + ix) + (uint32_t)p.map_x * ((uint32_t)(by0 + iy) + (uint32_t)p.map_y * (uint32_t)(bz0 + iz));
+      marked = marked || ((p.map[b >> 5] >> (b & 31u)) & 1u);
+    }
+    if (__builtin_amdgcn_ballot_w64(marked) == 0)
+    {
+      const int n_sub = (vz1 - vz0 + p.z_sub - 1) / p.z_sub;
+      if (lane < n_sub)
+        counts[tile + (size_t)lane * tile_stride] = 0;
+      return;
+    }
+  }
   unsigned long long out = 0;
   if (EMIT)
   {
@@ -594,7 +622,8 @@ static int tile_scratch(yakhip_ctx* ctx, size_t n_tiles, uint32_t** counts, uint
                         unsigned long long** block_bases, unsigned long long** total, size_t* n_blocks_out);
 
 int launch_marching_cubes(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int z0, int layers, int min_weight,
-                          double scale, float* triangles, unsigned long long capacity, unsigned long long* n_out)
+                          double scale, float* triangles, unsigned long long capacity, unsigned long long* n_out,
+                          const uint32_t* map, int map_z0)
 {
   *n_out = 0;
   if (X < 2 || Y < 2 || layers < 2)
@@ -617,6 +646,8 @@ int launch_marching_cubes(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, in
   p.nzc = (p.cube_layers + p.z_chunk - 1) / p.z_chunk;
   p.min_weight = min_weight;
   p.scale = scale;
+  p.map = ctx->surface_skip ? map : nullptr;
+  p.map_x = (X + 15) >> 4, p.map_y = (Y + 15) >> 4, p.map_z0 = map_z0;
   const unsigned gy = (unsigned)((p.ny + 3) / 4);
   if (gy > 65535u)
     return fail(YAKHIP_ERANGE, "marching_cubes: more than a million voxel rows");

@@ -237,7 +237,9 @@ int launch_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], c
 int launch_weld(yakhip_ctx* ctx, const uint32_t* corners, uint32_t n, uint32_t* vertices, uint32_t* index,
                 unsigned long long* n_vertices_host);
 int launch_marching_cubes(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int z0, int layers, int min_weight,
-                          double scale, float* triangles, unsigned long long capacity, unsigned long long* n_out);
+                          double scale, float* triangles, unsigned long long capacity, unsigned long long* n_out,
+                          const uint32_t* map = nullptr, int map_z0 = 0);
+// (map: the surface map of the slab these layers are part of, whose layer map_z0 is `vol`'s first; nullptr: read everything)
 int launch_extract_cloud(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int z0, int layers, const float vs[3],
                          const float R[9], const float t[3], float* points, unsigned long long capacity,
                          unsigned long long* n_out);
