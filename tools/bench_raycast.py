@@ -10,6 +10,18 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def phase_cycles(capi):
+    """Phase sums of a library built with EXTRA=-DYAK_RAYCAST_TIMING (None otherwise); resets them."""
+    import ctypes
+    try:
+        fn = capi.load().yakhip_debug_raycast_timing
+    except AttributeError:
+        return None
+    out = (ctypes.c_ulonglong * 10)()
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    return list(out) if fn(out, 1) == 0 else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=512)
@@ -63,15 +75,23 @@ def main():
                                               synth.COLS * 16, nrm.data_ptr(), synth.COLS * 16, synth.ROWS, synth.COLS)
             for _ in range(3):
                 call()
+            phase_cycles(capi)
             ctx.set_option("kernel_timing", 1)
             for _ in range(args.reps):
                 call()
             ms, k = ctx.kernel_time()
             ctx.set_option("kernel_timing", 0)
+            phases = phase_cycles(capi)
             hits = int((~torch.isnan(pts[..., 0])).sum().item())
             results.append((pts.clone(), nrm.clone()))
             print("view %3d %-6s: raycast_kernel %.4f ms (mean of %d), %d hits of %d rays" % (view, name, ms / k, k, hits,
                                                                                            synth.ROWS * synth.COLS), flush=True)
+            if phases:
+                w = max(phases[5], 1)
+                print("   per wave (cycles): map fill %.0f, entry + cell walk %.0f, %.1f trips %.0f (of them %.1f with a fetch: %.0f), "
+                      "hit %.0f; %.1f hits per wave; longest wave %d"
+                      % (phases[0] / w, phases[1] / w, phases[4] / w, phases[2] / w, phases[8] / w, phases[9] / w, phases[3] / w,
+                         phases[6] / w, phases[7]), flush=True)
         same = all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(results[0], results[1]))
         print("view %3d: maps with and without the surface map are %s" % (view, "bit-identical" if same else "DIFFERENT"), flush=True)
     ctx.close()

@@ -95,13 +95,22 @@ __device__ __forceinline__ float fetch_tsdf(const RaycastParams& p, float px, fl
 constexpr int kSkipShift = 4;  // YAKHIP_SURFACE_BRICK = 16
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
+// min(max(v, 0), hi) for a wave-uniform hi >= 0 in one instruction (the compiler cannot know hi >= 0 and emits two)
+__device__ __forceinline__ int clamp_index(int v, int hi)
+{
+  int r;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "s"(hi));
+  return r;
+}
+// (index arithmetic in 24-bit multiply-adds, full rate where the 32-bit ones run at a quarter: the launcher takes this
+// variant only for X, Y < 2^24 and Y * held layers <= 2^24)
 template <bool SLAB>
 __device__ __forceinline__ float fetch_tsdf_skip(const RaycastParams& p, rsrc_t rs, const uint32_t* map_lds, float px, float py,
                                                  float pz, bool& owned, bool& held, bool& skipped)
 {
-  const int x = clampi((int)__builtin_rintf(px * p.ivx), p.X - 1);
-  const int y = clampi((int)__builtin_rintf(py * p.ivy), p.Y - 1);
-  const int z = clampi((int)__builtin_rintf(pz * p.ivz), p.Z - 1);
+  const int x = clamp_index((int)__builtin_rintf(px * p.ivx), p.X - 1);
+  const int y = clamp_index((int)__builtin_rintf(py * p.ivy), p.Y - 1);
+  const int z = clamp_index((int)__builtin_rintf(pz * p.ivz), p.Z - 1);
   int zl = z;
   bool in = true;
   if constexpr (SLAB)
@@ -113,10 +122,10 @@ __device__ __forceinline__ float fetch_tsdf_skip(const RaycastParams& p, rsrc_t 
     zl = in ? zl : 0;
   }
   const uint32_t b = (uint32_t)(x >> kSkipShift) +
-                     (uint32_t)p.skip_x * ((uint32_t)(y >> kSkipShift) + (uint32_t)p.skip_y * (uint32_t)(zl >> kSkipShift));
+                     __umul24((uint32_t)p.skip_x, (uint32_t)(y >> kSkipShift) + __umul24((uint32_t)p.skip_y, (uint32_t)(zl >> kSkipShift)));
   const bool marked = (map_lds[b >> 5] >> (b & 31u)) & 1u;
   skipped = in && !marked;
-  const uint32_t idx = (uint32_t)x + (uint32_t)p.X * ((uint32_t)y + (uint32_t)p.Y * (uint32_t)zl);
+  const uint32_t idx = (uint32_t)x + __umul24((uint32_t)p.X, (uint32_t)y + __umul24((uint32_t)p.Y, (uint32_t)zl));
   const uint32_t word = __builtin_amdgcn_raw_buffer_load_b32(rs, in && marked ? idx << 2 : 0x80000000u, 0, 0);
   return half_bits_to_float(word & 0xffffu);
 }
@@ -176,8 +185,19 @@ __device__ __forceinline__ void surface_gradient(const RaycastParams& p, float p
   normalize3(gx, gy, gz);
 }
 
+#ifdef YAK_RAYCAST_TIMING
+// diagnostic build only (make EXTRA=-DYAK_RAYCAST_TIMING; tools/bench_raycast.py prints the sums): shader-clock cycles
+// per phase of every wave of the last launch
+constexpr int kRcSlots = 8192;
+__device__ unsigned long long g_rc_time[kRcSlots][10];
+#define RC_CLOCK(var) var = __builtin_readcyclecounter()
+#define RC_COUNT(var) var += 1
+#else
+#define RC_CLOCK(var)
+#define RC_COUNT(var)
+#endif
 template <bool IDX32, bool SLAB, bool SKIP>
-__global__ __launch_bounds__(256) void raycast_kernel(const RaycastParams p, int tiles_x, int n_tiles, int per_xcd)
+__global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, int tiles_x, int n_tiles, int per_xcd)
 {
   // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; give each XCD a
   // contiguous run of tiles (a band of the image) so that its L2 sees one part of the volume.
@@ -187,6 +207,10 @@ __global__ __launch_bounds__(256) void raycast_kernel(const RaycastParams p, int
   const int tile = per_xcd > 0 ? (bid & 7) * per_xcd + (bid >> 3) : (per_xcd < 0 ? (int)(((long long)bid * -per_xcd) % n_tiles) : bid);
   if (tile >= n_tiles)
     return;
+#ifdef YAK_RAYCAST_TIMING
+  unsigned long long rc_t0, rc_t1, rc_t2, rc_t3, rc_trips = 0, rc_real = 0, rc_real_cycles = 0, rc_trip0 = 0, rc_trip1 = 0;
+  RC_CLOCK(rc_t0);
+#endif
   extern __shared__ uint32_t map_lds[];
   if constexpr (SKIP)
   {
@@ -201,6 +225,8 @@ __global__ __launch_bounds__(256) void raycast_kernel(const RaycastParams p, int
   if (x >= p.cols || y >= p.rows)
     return;
 
+  RC_CLOCK(rc_t1);
+  RC_CLOCK(rc_t2);
   // tsdf_volume.cu:300-301; device.hpp:57-62 with z = 1
   const float rx = ((float)x - p.cx) * p.finvx;
   const float ry = ((float)y - p.cy) * p.finvy;
@@ -326,8 +352,11 @@ __global__ __launch_bounds__(256) void raycast_kernel(const RaycastParams p, int
         }
       }
     }
+    RC_CLOCK(rc_t2);
     while (state == 0)
     {
+      RC_COUNT(rc_trips);
+      RC_CLOCK(rc_trip0);
       constexpr int kUnroll = SKIP ? YAK_RAYCAST_UNROLL_SKIP : kUnrollPlain;
       float qx[kUnroll], qy[kUnroll], qz[kUnroll], f[kUnroll];
       bool own[kUnroll], held[kUnroll], skip[kUnroll];
@@ -345,47 +374,106 @@ __global__ __launch_bounds__(256) void raycast_kernel(const RaycastParams p, int
         else
           f[k] = fetch_tsdf<IDX32, SLAB>(p, ax, ay, az, own[k], held[k]);
       }
-      float cx = nx, cy = ny, cz = nz, fc = tsdf_next;
-      bool own_c = own_next, skip_c = skip_next;
-#pragma unroll
-      for (int k = 0; k < kUnroll; ++k)
+      if constexpr (SKIP)
       {
-        if (state == 0)
+        // A skipped sample reads as +0 and is >= 0; its value matters only beside a negative one (tsdf_volume.cu:326-331:
+        // a pair ends the march only if one of its samples is negative).  A lane with such a pair in this trip fetches
+        // all the trip's samples for good, in one go: one wait for the wave.
+        bool beside_negative = (skip_next & (f[0] < 0.f)) | (skip[0] & (tsdf_next < 0.f));
+#pragma unroll
+        for (int k = 1; k < kUnroll; ++k)
+          beside_negative = beside_negative | (skip[k - 1] & (f[k] < 0.f)) | (skip[k] & (f[k - 1] < 0.f));
+        if (beside_negative)
         {
-          if constexpr (SKIP)
+          bool o = true, h = true;
+          tsdf_next = fetch_tsdf<IDX32, SLAB>(p, nx, ny, nz, o, h);
+          skip_next = false;
+#pragma unroll
+          for (int k = 0; k < kUnroll; ++k)
           {
-            // a skipped sample is >= 0; its value matters only beside a negative one (tsdf_volume.cu:326-331)
-            bool o = true, h = true;
-            if (skip_c && f[k] < 0.f)
-              fc = fetch_tsdf<IDX32, SLAB>(p, cx, cy, cz, o, h);
-            if (skip[k] && fc < 0.f)
-            {
-              f[k] = fetch_tsdf<IDX32, SLAB>(p, qx[k], qy[k], qz[k], o, h);
-              skip[k] = false;
-            }
-          }
-          if (!(tcurr < tmax))
-            state = 2;
-          else if (own_c && fc < 0.f && f[k] > 0.f)
-            state = 3;
-          else if (own_c && fc > 0.f && f[k] < 0.f)
-          {
-            state = 1;
-            hcx = cx, hcy = cy, hcz = cz;
-            hnx = qx[k], hny = qy[k], hnz = qz[k];
-          }
-          else
-          {
-            tcurr += ts;
-            ++pair;
+            f[k] = fetch_tsdf<IDX32, SLAB>(p, qx[k], qy[k], qz[k], o, h);
+            skip[k] = false;
           }
         }
-        cx = qx[k], cy = qy[k], cz = qz[k], fc = f[k], own_c = own[k], skip_c = skip[k];
+        // The pairs in order, without branches (the lanes of a wave end their marches at different pairs): `ended` is
+        // the first pair that ends the march, by running out of time (2), a zero crossing (1) or the - to + abort (3).
+        float fc = tsdf_next;
+        bool own_c = own_next;
+        int ended = -1;
+#pragma unroll
+        for (int k = 0; k < kUnroll; ++k)
+        {
+          // (& and |, not && and ||: masks, no short cuts)
+          const bool marching = state == 0;
+          const bool late = !(tcurr < tmax);
+          const bool abort = own_c & (fc < 0.f) & (f[k] > 0.f), crossing = own_c & (fc > 0.f) & (f[k] < 0.f);
+          const int verdict = late ? 2 : (abort ? 3 : (crossing ? 1 : 0));
+          const bool on = marching & !(late | abort | crossing);
+          tcurr = on ? tcurr + ts : tcurr;
+          pair += on ? 1 : 0;
+          ended = (marching & !on) ? k : ended;
+          state = marching ? verdict : state;
+          fc = f[k], own_c = own[k];
+        }
+        if (state == 1)
+        {
+          // the bracketing samples of the hit: pair `ended` = samples ended - 1 and ended of this trip
+          hcx = nx, hcy = ny, hcz = nz;
+#pragma unroll
+          for (int k = 0; k < kUnroll; ++k)
+          {
+            hcx = ended == k + 1 ? qx[k] : hcx, hcy = ended == k + 1 ? qy[k] : hcy, hcz = ended == k + 1 ? qz[k] : hcz;
+            hnx = ended == k ? qx[k] : hnx, hny = ended == k ? qy[k] : hny, hnz = ended == k ? qz[k] : hnz;
+          }
+        }
       }
-      nx = cx, ny = cy, nz = cz, tsdf_next = fc, own_next = own_c, skip_next = skip_c;
+      else
+      {
+        // pair by pair, as the loads arrive (this variant waits for memory, not for the vector unit)
+        float cx = nx, cy = ny, cz = nz, fc = tsdf_next;
+        bool own_c = own_next;
+#pragma unroll
+        for (int k = 0; k < kUnroll; ++k)
+        {
+          if (state == 0)
+          {
+            if (!(tcurr < tmax))
+              state = 2;
+            else if (own_c && fc < 0.f && f[k] > 0.f)
+              state = 3;
+            else if (own_c && fc > 0.f && f[k] < 0.f)
+            {
+              state = 1;
+              hcx = cx, hcy = cy, hcz = cz;
+              hnx = qx[k], hny = qy[k], hnz = qz[k];
+            }
+            else
+            {
+              tcurr += ts;
+              ++pair;
+            }
+          }
+          cx = qx[k], cy = qy[k], cz = qz[k], fc = f[k], own_c = own[k];
+        }
+      }
+      nx = qx[kUnroll - 1], ny = qy[kUnroll - 1], nz = qz[kUnroll - 1];
+      tsdf_next = f[kUnroll - 1], own_next = own[kUnroll - 1], skip_next = skip[kUnroll - 1];
+#ifdef YAK_RAYCAST_TIMING
+      if constexpr (SKIP)
+      {
+        bool fetched = false;
+#pragma unroll
+        for (int k = 0; k < kUnroll; ++k)
+          fetched = fetched || !skip[k];
+        RC_CLOCK(rc_trip1);
+        if (__ballot(fetched) != 0ull)  // the wave waited for memory in this trip
+          rc_real += 1, rc_real_cycles += rc_trip1 - rc_trip0;
+      }
+#endif
     }
   }
 
+  RC_CLOCK(rc_t3);
   const float qnan = __builtin_nanf("");
   float vx = qnan, vy = qnan, vz = qnan, vw = qnan, n0 = qnan, n1 = qnan, n2 = qnan, n3 = qnan;
   bool hit = false, deferred = false;
@@ -440,6 +528,25 @@ __global__ __launch_bounds__(256) void raycast_kernel(const RaycastParams p, int
     unsigned short* drow = (unsigned short*)(p.depth + (size_t)y * p.depth_pitch);
     drow[x] = mm_out;
   }
+#ifdef YAK_RAYCAST_TIMING
+  {
+    const unsigned long long rc_t4 = __builtin_readcyclecounter();
+    const unsigned long long hits = __builtin_popcountll(__ballot(state == 1));
+    // the march loop is left lane by lane: the wave's figures are those of the lane that stayed longest
+    for (int off = 32; off >= 1; off >>= 1)
+    {
+      rc_trips = max(rc_trips, (unsigned long long)__shfl_xor((unsigned)rc_trips, off, 64));
+      rc_real = max(rc_real, (unsigned long long)__shfl_xor((unsigned)rc_real, off, 64));
+      rc_real_cycles = max(rc_real_cycles, (unsigned long long)__shfl_xor((unsigned)rc_real_cycles, off, 64));
+    }
+    if (lane == 0)  // (a wave whose lane 0 is outside the image reports nothing)
+    {
+      unsigned long long* row = g_rc_time[((int)blockIdx.x * 4 + wave) & (kRcSlots - 1)];
+      row[0] = rc_t1 - rc_t0, row[1] = rc_t2 - rc_t1, row[2] = rc_t3 - rc_t2, row[3] = rc_t4 - rc_t3;
+      row[4] = rc_trips, row[5] = 1ull, row[6] = hits, row[7] = rc_t4 - rc_t0, row[8] = rc_real, row[9] = rc_real_cycles;
+    }
+  }
+#endif
   if constexpr (SLAB)
   {
     // the pair that ended the march here (zero crossing = 1, abort = 3), or "none": 2 * k + (1 if the
@@ -563,6 +670,25 @@ __global__ __launch_bounds__(256) void surface_scan_kernel(const uint32_t* vol, 
 }
 }  // namespace
 
+#ifdef YAK_RAYCAST_TIMING
+// sums over the waves of the last launch (entry 7: the longest wave); reset clears the rows
+extern "C" int yakhip_debug_raycast_timing(unsigned long long out[10], int reset)
+{
+  static unsigned long long rows[kRcSlots][10];
+  void* at = nullptr;
+  if (hipDeviceSynchronize() != hipSuccess || hipGetSymbolAddress(&at, HIP_SYMBOL(g_rc_time)) != hipSuccess ||
+      hipMemcpy(rows, at, sizeof(rows), hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  for (int k = 0; k < 10; ++k)
+    out[k] = 0;
+  for (int w = 0; w < kRcSlots; ++w)
+    for (int k = 0; k < 10; ++k)
+      out[k] = k == 7 ? (rows[w][k] > out[k] ? rows[w][k] : out[k]) : out[k] + rows[w][k];
+  if (reset && hipMemset(at, 0, sizeof(rows)) != hipSuccess)
+    return -1;
+  return 0;
+}
+#endif
 int launch_surface_scan(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int layers, uint32_t* map)
 {
   const int bx = (X + 15) >> 4, by = (Y + 15) >> 4, bz = (layers + 15) >> 4;
@@ -624,8 +750,9 @@ int launch_raycast(yakhip_ctx* ctx, const RaycastParams& p)
   if (rc != 0)
     return rc;
   // the surface map travels in LDS: volumes whose map is too large for that are marched without it
+  // (and it does its index arithmetic in 24 bits: fetch_tsdf_skip)
   const bool skip = p.skip != nullptr && p.skip_words + p.cell_words <= kMaxSkipWords && p.vol_bytes < 0x80000000ull &&
-                    ctx->surface_skip;
+                    p.X < (1 << 24) && p.Y < (1 << 24) && (long long)p.Y * p.z_held <= (1ll << 24) && ctx->surface_skip;
   const size_t lds = skip ? (size_t)(p.skip_words + p.cell_words) * 4u : 0;
 #define YAK_RAYCAST_LAUNCH(I, S)                                                                                    \
   do                                                                                                               \
