@@ -22,6 +22,18 @@ def phase_cycles(capi):
     return list(out) if fn(out, 1) == 0 else None
 
 
+def wave_rows(capi):
+    import ctypes
+    try:
+        fn = capi.load().yakhip_debug_raycast_rows
+    except AttributeError:
+        return None
+    out = np.zeros((8192, 10), dtype=np.uint64)
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    n = fn(out.ctypes.data, 8192)
+    return out[:n] if n > 0 else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=512)
@@ -81,6 +93,7 @@ def main():
                 call()
             ms, k = ctx.kernel_time()
             ctx.set_option("kernel_timing", 0)
+            rows = wave_rows(capi)
             phases = phase_cycles(capi)
             hits = int((~torch.isnan(pts[..., 0])).sum().item())
             results.append((pts.clone(), nrm.clone()))
@@ -92,6 +105,13 @@ def main():
                       "hit %.0f; %.1f hits per wave; longest wave %d"
                       % (phases[0] / w, phases[1] / w, phases[4] / w, phases[2] / w, phases[8] / w, phases[9] / w, phases[3] / w,
                          phases[6] / w, phases[7]), flush=True)
+                if rows is not None and name == "map":
+                    live = rows[rows[:, 5] > 0]
+                    order = np.argsort(-live[:, 7].astype(np.int64))
+                    print("   waves by lifetime (cycles: total / cell walk / march / hit; trips, trips with a fetch, hits):")
+                    for q in (0, 1, 2, len(order) // 100, len(order) // 10, len(order) // 2, len(order) * 9 // 10):
+                        r = live[order[q]]
+                        print("     #%-5d %7d / %6d / %7d / %6d; %3d %3d %2d" % (q, r[7], r[1], r[2], r[3], r[4], r[8], r[6]), flush=True)
         same = all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(results[0], results[1]))
         print("view %3d: maps with and without the surface map are %s" % (view, "bit-identical" if same else "DIFFERENT"), flush=True)
     ctx.close()

@@ -688,6 +688,16 @@ extern "C" int yakhip_debug_raycast_timing(unsigned long long out[10], int reset
     return -1;
   return 0;
 }
+// the rows themselves (kRcSlots x 10), for a closer look at the waves that take longest
+extern "C" int yakhip_debug_raycast_rows(unsigned long long* out, int max_rows)
+{
+  void* at = nullptr;
+  const int n = max_rows < kRcSlots ? max_rows : kRcSlots;
+  if (hipDeviceSynchronize() != hipSuccess || hipGetSymbolAddress(&at, HIP_SYMBOL(g_rc_time)) != hipSuccess ||
+      hipMemcpy(out, at, (size_t)n * 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  return n;
+}
 #endif
 int launch_surface_scan(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int layers, uint32_t* map)
 {
