@@ -53,9 +53,12 @@ struct IcpParams
   int row0;
 };
 
+// (the offset in 32 bits from a 24-bit multiply: one full-rate instruction where the 64-bit form takes two at a
+// quarter of the rate, on the path between the pose and the gather; the launchers check rows, pitch < 2^24 and
+// rows * pitch < 2^32)
 __device__ __forceinline__ float4 f4_at(const uint8_t* base, uint32_t pitch, int y, int x)
 {
-  return ((const float4*)(base + (size_t)y * pitch))[x];
+  return *(const float4*)(base + (__umul24((uint32_t)y, pitch) + ((uint32_t)x << 4)));
 }
 
 // Sum over the 64 lanes of a wave without touching LDS: six v_add_f32 with DPP operands (quad swaps, row
@@ -329,15 +332,25 @@ struct CurrentMaps
 __device__ __forceinline__ void load_current(const IcpParams& p, int block, int tid, CurrentMaps& c)
 {
   const int n_pixels = p.rows * p.cols;
-  const int base = block * (256 * kPixelsPerLane) + tid;
+  const int last = n_pixels > 0 ? n_pixels - 1 : 0;  // (an empty band of the sharded schedule: pixel (row0, 0), a valid row)
+  // Row and column of the block's first pixel: one integer division per wave (`block` is the same in all its lanes).
+  // The lanes' pixels lie at most 1023 further on: their rows and columns come from a float quotient of numbers
+  // below 2^24, put right by one either way -- a handful of full-rate instructions per pixel where the 32-bit
+  // division takes some thirty, a third of them at a quarter of the rate, in front of the first load.
+  const int first = min(__builtin_amdgcn_readfirstlane(block) * (256 * kPixelsPerLane), last);
+  const int row_first = first / p.cols, col_first = first - row_first * p.cols;
+  const float inv_cols = __builtin_amdgcn_rcpf((float)p.cols);
 #pragma unroll
   for (int i = 0; i < kPixelsPerLane; ++i)
   {
-    const int pix = base + i * 256;
+    const int pix = first + tid + i * 256;
     c.live[i] = pix < n_pixels;
-    const int pc = c.live[i] ? pix : (n_pixels > 0 ? n_pixels - 1 : 0);  // a dead lane re-reads the band's last pixel (an empty
-                                                                         // band of the sharded schedule: pixel (row0, 0), a valid row)
-    const int yr = pc / p.cols, x = pc - yr * p.cols, y = yr + p.row0;
+    const int col = col_first + ((c.live[i] ? pix : last) - first);  // a dead lane re-reads the band's last pixel
+    int q = (int)((float)col * inv_cols);
+    int x = col - (int)__umul24((uint32_t)q, (uint32_t)p.cols);
+    q += x < 0 ? -1 : (x >= p.cols ? 1 : 0);
+    x += x < 0 ? p.cols : (x >= p.cols ? -p.cols : 0);
+    const int y = row_first + q + p.row0;
     c.s0[i] = f4_at(p.vcurr, p.vcurr_pitch, y, x);
     c.nc[i] = f4_at(p.ncurr, p.ncurr_pitch, y, x);
   }
@@ -561,6 +574,16 @@ __global__ __launch_bounds__(1024) void icp_solve_kernel(const float* partial, i
 
 static int icp_scratch(yakhip_ctx* ctx, size_t need);
 
+// what the kernels' 24-bit index arithmetic needs (f4_at, load_current): far beyond any camera
+static bool icp_fits(int rows, int cols, size_t pitch_a, size_t pitch_b, size_t pitch_c, size_t pitch_d)
+{
+  size_t pitch = pitch_a > pitch_b ? pitch_a : pitch_b;
+  pitch = pitch > pitch_c ? pitch : pitch_c;
+  pitch = pitch > pitch_d ? pitch : pitch_d;
+  return (long long)rows * cols <= 0x7fffffffll - 2048 && rows < (1 << 24) && cols < (1 << 22) && pitch < (1u << 24) &&
+         (unsigned long long)rows * pitch < (1ull << 32);
+}
+
 int launch_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], int level,
                           float dist_thres, float angle_thres, const uint8_t* vcurr, size_t vcurr_pitch,
                           const uint8_t* ncurr, size_t ncurr_pitch, const uint8_t* vprev, size_t vprev_pitch,
@@ -584,7 +607,7 @@ int launch_icp_accumulate(yakhip_ctx* ctx, const float R[9], const float t[3], c
   p.rows = row_end - row_begin, p.cols = cols, p.row0 = row_begin;
 
   const long long n_pixels = (long long)p.rows * cols;
-  if ((long long)rows * cols > 0x7fffffffll - 2048)
+  if (!icp_fits(rows, cols, vcurr_pitch, ncurr_pitch, vprev_pitch, nprev_pitch))
     return fail(YAKHIP_ERANGE, "icp: image too large");
   if (n_pixels == 0)  // an empty row range (a rank with no rows of a coarse level): all sums are zero
     return check(hipMemsetAsync(sums_dev, 0, kValues * sizeof(float), ctx->stream), "hipMemsetAsync");
@@ -658,7 +681,8 @@ int launch_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], con
   for (int l = 0; l < n_levels; ++l)
   {
     const long long n_pixels = (long long)levels[l].rows * levels[l].cols;
-    if (n_pixels > 0x7fffffffll - 2048)
+    if (!icp_fits(levels[l].rows, levels[l].cols, levels[l].vcurr_pitch, levels[l].ncurr_pitch, levels[l].vprev_pitch,
+                  levels[l].nprev_pitch))
       return fail(YAKHIP_ERANGE, "icp: image too large");
     const int nb = (int)((n_pixels + 256 * kPixelsPerLane - 1) / (256 * kPixelsPerLane));
     if (nb > max_blocks)
@@ -780,7 +804,8 @@ int launch_icp_estimate_sharded(yakhip_ctx* ctx, yakhip_comm* comm, const float 
   for (int l = 0; l < n_levels; ++l)
   {
     const long long n_pixels = (long long)levels[l].rows * levels[l].cols;
-    if (n_pixels > 0x7fffffffll - 2048)
+    if (!icp_fits(levels[l].rows, levels[l].cols, levels[l].vcurr_pitch, levels[l].ncurr_pitch, levels[l].vprev_pitch,
+                  levels[l].nprev_pitch))
       return fail(YAKHIP_ERANGE, "icp: image too large");
     const int nb = (int)((n_pixels + 256 * kPixelsPerLane - 1) / (256 * kPixelsPerLane));
     if (nb > max_blocks)
