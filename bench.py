@@ -568,7 +568,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # (YAK_BENCH_FORCE_PG=1: the process group also for one rank -- the RCCL branch rehearsed on a one-GPU box,
+    # tests/test_bench_ranks_gpu.py)
+    if world > 1 or os.environ.get("YAK_BENCH_FORCE_PG") == "1":
         import torch.distributed as dist
 
         if share_gpu:

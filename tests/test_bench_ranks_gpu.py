@@ -1,6 +1,8 @@
 """bench.py's N > 1 path, rehearsed on one GPU: two ranks launched by torch.distributed.run exactly as the
 driver launches them, both on GPU 0 and over gloo (YAK_BENCH_SHARE_GPU=1; RCCL refuses two ranks on one
-device).  Checks the contract of the one JSON line: whole-job value, max-over-ranks time, weak scaling."""
+device).  Checks the contract of the one JSON line: whole-job value, max-over-ranks time, weak scaling.
+And the RCCL branch itself (init_process_group("nccl", device_id=...), barrier, all_reduce of CUDA tensors) with
+the one rank a one-GPU box allows."""
 import json
 import os
 import socket
@@ -34,3 +36,21 @@ def test_two_ranks_through_torch_distributed_run():
     # value = all ranks' voxels over the slowest rank's time
     assert abs(d["value"] - 2 * 512 ** 3 / (d["ms_per_step"] * 1e-3) / 1e9) < 0.01 * d["value"]
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+
+
+def test_one_rank_over_rccl():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, YAK_BENCH_FORCE_PG="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "3",
+           "--no-rows", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["voxels_updated_per_step"] == 512 ** 3
+    assert abs(d["value"] - 512 ** 3 / (d["ms_per_step"] * 1e-3) / 1e9) < 0.01 * d["value"]
