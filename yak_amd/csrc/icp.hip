@@ -519,6 +519,20 @@ __global__ __launch_bounds__(256 * NB) void icp_accumulate_kernel(const IcpParam
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       t[i] = p.t[i];
+    // the first launch of a device-resident estimate: the pose came with the launch (no copy command in front of
+    // the chain); it goes into the state slot the next launch starts from
+    if (p.state_out && blockIdx.x == 0 && threadIdx.x == 0)
+    {
+      IcpState st;
+#pragma unroll
+      for (int i = 0; i < 9; ++i)
+        st.R[i] = p.R[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        st.t[i] = p.t[i];
+      st.status = 0, st.iterations = 0;
+      *p.state_out = st;
+    }
   }
 
   if (exists)
@@ -708,7 +722,6 @@ int launch_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], con
   host->iterations = 0;
   if (n_launches > 0)
   {
-    YAKHIP_TRY(hipMemcpyAsync(&slots[0], host, sizeof(IcpState), hipMemcpyHostToDevice, ctx->stream));
     int j = 0, prev_blocks = 0;
     for (int l = n_levels - 1; l >= 0; --l)
     {
@@ -733,9 +746,17 @@ int launch_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], con
       const int n_blocks = (int)(((long long)L.rows * L.cols + 256 * kPixelsPerLane - 1) / (256 * kPixelsPerLane));
       for (int it = 0; it < L.iterations; ++it, ++j)
       {
-        // launch 0 takes slot 0 as it is; launch j > 0 turns slot j - 1 and launch j - 1's partials into slot j
-        p.state = j == 0 ? &slots[0] : &slots[j - 1];
+        // launch 0 takes the pose from its arguments and records it in slot 0; launch j > 0 turns slot j - 1 and
+        // launch j - 1's partials into slot j
+        p.state = j == 0 ? nullptr : &slots[j - 1];
         p.state_out = &slots[j];
+        if (j == 0)
+        {
+          for (int i = 0; i < 9; ++i)
+            p.R[i] = R[i];
+          for (int i = 0; i < 3; ++i)
+            p.t[i] = t[i];
+        }
         p.prev_partial = j == 0 ? nullptr : partial[(j - 1) & 1];
         p.prev_blocks = prev_blocks;
         hipLaunchKernelGGL(icp_accumulate_kernel<YAK_ICP_NB>, dim3((unsigned)((n_blocks + YAK_ICP_NB - 1) / YAK_ICP_NB)), dim3(256 * YAK_ICP_NB), 0, ctx->stream, p, partial[j & 1],
