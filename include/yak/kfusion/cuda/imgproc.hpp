@@ -19,6 +19,10 @@ KF_EXPORTS void depthBuildPyramid(const Depth& depth, Depth& pyramid, float sigm
 KF_EXPORTS void computePointNormals(const Intr& intr, const Depth& depth, Cloud& points, Normals& normals);
 /** 2 x 2 box average of point / normal maps (reference imgproc.cpp:65-80, imgproc.cu:348-394). */
 KF_EXPORTS void resizePointsNormals(const Cloud& points, const Normals& normals, Cloud& points_out, Normals& normals_out);
+/** Two levels in one launch (no counterpart in the reference, which calls resizePointsNormals level by level:
+ *  kinfu.cpp:294-306): the same maps, bit for bit. */
+KF_EXPORTS void resizePointsNormals2(const Cloud& points, const Normals& normals, Cloud& points_half, Normals& normals_half,
+                                     Cloud& points_quarter, Normals& normals_quarter);
 /** Debug views, 4 bytes per pixel {b, g, r, 0}; both block like the reference's (imgproc.cpp:82-126,
  *  imgproc.cu:400-561).  renderImage: Phong shading of camera-frame maps lit from light_pose; the Depth
  *  overload re-projects with (fx, fy, cx, fy) exactly as imgproc.cpp:92 builds its Reprojector. */

@@ -369,6 +369,13 @@ int yakhip_compute_points_normals(yakhip_ctx* ctx, const float intr[4], const vo
 int yakhip_resize_points_normals(yakhip_ctx* ctx, const void* points_dev, size_t points_pitch, const void* normals_dev,
                                  size_t normals_pitch, int src_rows, int src_cols, void* points_out_dev,
                                  size_t points_out_pitch, void* normals_out_dev, size_t normals_out_pitch);
+/* The same twice in one launch, for the three-level model pyramid after a ray cast (kinfu.cpp:294-306 calls
+ * resizePointsNormals level by level): half-size maps (src / 2) and quarter-size maps ((src / 2) / 2), bit for bit
+ * those of two calls.  No counterpart of its own in the reference. */
+int yakhip_resize_points_normals2(yakhip_ctx* ctx, const void* points_dev, size_t points_pitch, const void* normals_dev,
+                                  size_t normals_pitch, int src_rows, int src_cols, void* points1_dev, size_t points1_pitch,
+                                  void* normals1_dev, size_t normals1_pitch, void* points2_dev, size_t points2_pitch,
+                                  void* normals2_dev, size_t normals2_pitch);
 /* Replaces kfusion::device::ComputeIcpHelper::operator() (Points overload, internal.hpp:113;
  * yak/src/cuda/proj_icp.cu:74-102, 105-387, 416-439) together with the stream synchronisation of
  * StreamHelper::get (yak/src/kfusion/projective_icp.cpp:42-61): BLOCKING.  For the pose estimate R,t

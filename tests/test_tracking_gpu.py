@@ -145,6 +145,28 @@ def test_points_normals_and_resize(gpu_ctx):
         assert same_maps(op.cpu().numpy(), wp) and same_maps(on.cpu().numpy(), wn)
         cur_p, cur_n, dp, dn = wp, wn, op, on
 
+    # ... and two levels in one launch (yakhip_resize_points_normals2): the bits of two calls, also where the
+    # half-size image has odd dimensions (its last row / column has no quarter-size pixel above it)
+    for r, c in ((want_p.shape[0], want_p.shape[1]), (38, 54), (37, 51), (5, 4)):
+        src_p, src_n = np.ascontiguousarray(want_p[:r, :c]), np.ascontiguousarray(want_n[:r, :c])
+        h_p, h_n = oracle.resize_points_normals(src_p, src_n)
+        q_p, q_n = oracle.resize_points_normals(h_p, h_n)
+        dp, dn = dev_f4(src_p), dev_f4(src_n)
+        o1p = torch.full((r // 2, c // 2 + 3, 4), 9.0, dtype=torch.float32, device="cuda")      # pitched rows
+        o1n, o2p = torch.full_like(o1p, 9.0), torch.full((r // 4, c // 4, 4), 9.0, dtype=torch.float32, device="cuda")
+        o2n = torch.full_like(o2p, 9.0)
+        gpu_ctx.resize_points_normals2(dp.data_ptr(), dp.stride(0) * 4, dn.data_ptr(), dn.stride(0) * 4, r, c,
+                                       o1p.data_ptr(), o1p.stride(0) * 4, o1n.data_ptr(), o1n.stride(0) * 4,
+                                       o2p.data_ptr(), o2p.stride(0) * 4, o2n.data_ptr(), o2n.stride(0) * 4)
+        torch.cuda.synchronize()
+        g1p, g1n = o1p.cpu().numpy(), o1n.cpu().numpy()
+        assert (g1p[:, c // 2:] == 9).all() and (g1n[:, c // 2:] == 9).all()
+        assert same_maps(g1p[:, :c // 2], h_p) and same_maps(g1n[:, :c // 2], h_n)
+        assert same_maps(o2p.cpu().numpy(), q_p) and same_maps(o2n.cpu().numpy(), q_n)
+    with pytest.raises(capi.YakHipError):
+        gpu_ctx.resize_points_normals2(dp.data_ptr(), 64, dn.data_ptr(), 64, 3, 4, o1p.data_ptr(), 64, o1n.data_ptr(), 64,
+                                       o2p.data_ptr(), 64, o2n.data_ptr(), 64)
+
 
 def level_maps(frame, level):
     depth, R, t = synth.scene_s2(frame, noise_mm=1.0)

@@ -20,7 +20,7 @@ EXPORTS = [
     "yakhip_integrate_batch",
     "yakhip_raycast_points", "yakhip_raycast_depth", "yakhip_raycast_slab", "yakhip_raycast_resolve", "yakhip_raycast_halo",
     "yakhip_bilateral_filter", "yakhip_truncate_depth", "yakhip_depth_pyramid", "yakhip_compute_points_normals",
-    "yakhip_resize_points_normals", "yakhip_icp_accumulate", "yakhip_icp_accumulate_rows", "yakhip_icp_estimate",
+    "yakhip_resize_points_normals", "yakhip_resize_points_normals2", "yakhip_icp_accumulate", "yakhip_icp_accumulate_rows", "yakhip_icp_estimate",
     "yakhip_marching_cubes", "yakhip_marching_cubes_layers", "yakhip_weld_vertices", "yakhip_extract_cloud", "yakhip_extract_normals",
     "yakhip_render_image_points", "yakhip_render_image_depth", "yakhip_render_tangent_colors",
     "yakhip_comm_unique_id", "yakhip_comm_create_rccl", "yakhip_comm_create_local", "yakhip_comm_create_custom",
@@ -133,6 +133,7 @@ def load():
         "yakhip_depth_pyramid": [vp, vp, sz, i, i, vp, sz, C.c_float],
         "yakhip_compute_points_normals": [vp, fp, vp, sz, i, i, vp, sz, vp, sz],
         "yakhip_resize_points_normals": [vp, vp, sz, vp, sz, i, i, vp, sz, vp, sz],
+        "yakhip_resize_points_normals2": [vp, vp, sz, vp, sz, i, i, vp, sz, vp, sz, vp, sz, vp, sz],
         "yakhip_icp_estimate": [vp, fp, fp, fp, C.c_float, C.c_float, C.POINTER(IcpLevel), i, fp, fp, C.POINTER(i)],
         "yakhip_marching_cubes": [vp, volp, i, C.c_double, vp, C.c_ulonglong, C.POINTER(C.c_ulonglong)],
         "yakhip_marching_cubes_layers": [vp, volp, i, i, i, C.c_double, vp, C.c_ulonglong, C.POINTER(C.c_ulonglong)],
@@ -363,6 +364,15 @@ class Context:
         _chk(load().yakhip_resize_points_normals(self._h, C.c_void_p(points_ptr), points_pitch, C.c_void_p(normals_ptr),
                                                  normals_pitch, src_rows, src_cols, C.c_void_p(points_out_ptr),
                                                  points_out_pitch, C.c_void_p(normals_out_ptr), normals_out_pitch))
+
+    def resize_points_normals2(self, points_ptr, points_pitch, normals_ptr, normals_pitch, src_rows, src_cols,
+                               points1_ptr, points1_pitch, normals1_ptr, normals1_pitch,
+                               points2_ptr, points2_pitch, normals2_ptr, normals2_pitch):
+        """Half- and quarter-size maps in one launch (the same bits as two resize_points_normals calls)."""
+        _chk(load().yakhip_resize_points_normals2(self._h, C.c_void_p(points_ptr), points_pitch, C.c_void_p(normals_ptr),
+                                                  normals_pitch, src_rows, src_cols, C.c_void_p(points1_ptr), points1_pitch,
+                                                  C.c_void_p(normals1_ptr), normals1_pitch, C.c_void_p(points2_ptr),
+                                                  points2_pitch, C.c_void_p(normals2_ptr), normals2_pitch))
 
     def icp_accumulate(self, R, t, intr, level, dist_thres, angle_thres, vcurr_ptr, vcurr_pitch, ncurr_ptr, ncurr_pitch,
                        vprev_ptr, vprev_pitch, nprev_ptr, nprev_pitch, rows, cols):

@@ -1221,6 +1221,35 @@ int yakhip_resize_points_normals(yakhip_ctx* ctx, const void* points_dev, size_t
                                       (uint8_t*)normals_out_dev, normals_out_pitch);
 }
 
+int yakhip_resize_points_normals2(yakhip_ctx* ctx, const void* points_dev, size_t points_pitch, const void* normals_dev,
+                                  size_t normals_pitch, int src_rows, int src_cols, void* points1_dev, size_t points1_pitch,
+                                  void* normals1_dev, size_t normals1_pitch, void* points2_dev, size_t points2_pitch,
+                                  void* normals2_dev, size_t normals2_pitch)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_image("resize_points_normals2(points)", points_dev, points_pitch, src_rows, src_cols, 16)) != 0)
+    return rc;
+  if ((rc = check_image("resize_points_normals2(normals)", normals_dev, normals_pitch, src_rows, src_cols, 16)) != 0)
+    return rc;
+  if (src_rows < 4 || src_cols < 4)
+    return fail(YAKHIP_EINVAL, "resize_points_normals2: source must be at least 4 x 4");
+  const int rows1 = src_rows / 2, cols1 = src_cols / 2, rows2 = rows1 / 2, cols2 = cols1 / 2;
+  if ((rc = check_image("resize_points_normals2(points, half size)", points1_dev, points1_pitch, rows1, cols1, 16)) != 0)
+    return rc;
+  if ((rc = check_image("resize_points_normals2(normals, half size)", normals1_dev, normals1_pitch, rows1, cols1, 16)) != 0)
+    return rc;
+  if ((rc = check_image("resize_points_normals2(points, quarter size)", points2_dev, points2_pitch, rows2, cols2, 16)) != 0)
+    return rc;
+  if ((rc = check_image("resize_points_normals2(normals, quarter size)", normals2_dev, normals2_pitch, rows2, cols2, 16)) != 0)
+    return rc;
+  return launch_resize_points_normals2(ctx, (const uint8_t*)points_dev, points_pitch, (const uint8_t*)normals_dev, normals_pitch,
+                                       src_rows, src_cols, (uint8_t*)points1_dev, points1_pitch, (uint8_t*)normals1_dev,
+                                       normals1_pitch, (uint8_t*)points2_dev, points2_pitch, (uint8_t*)normals2_dev,
+                                       normals2_pitch);
+}
+
 // ---- debug display -----------------------------------------------------------------------------
 
 static int render_image(yakhip_ctx* ctx, bool from_depth, const void* src_dev, size_t src_pitch, const void* normals_dev,

@@ -171,18 +171,12 @@ __device__ __forceinline__ float4 f4_at(const uint8_t* base, uint32_t pitch, int
   return ((const float4*)(base + (size_t)y * pitch))[x];
 }
 
-// imgproc.cu:348-380
-__global__ __launch_bounds__(256) void resize_points_normals_kernel(const uint8_t* vsrc, uint32_t vsrc_pitch,
-                                                                    const uint8_t* nsrc, uint32_t nsrc_pitch,
-                                                                    uint8_t* vdst, uint32_t vdst_pitch, uint8_t* ndst,
-                                                                    uint32_t ndst_pitch, int rows, int cols)
+// imgproc.cu:348-380: pixel (y, x) of the half-size maps from the 2 x 2 block of the source
+__device__ __forceinline__ void resize_pixel(const uint8_t* vsrc, uint32_t vsrc_pitch, const uint8_t* nsrc, uint32_t nsrc_pitch,
+                                             int y, int x, float4& v, float4& n)
 {
-  const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
-  const int y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
-  if (x >= cols || y >= rows)
-    return;
   const float qnan = __builtin_nanf("");
-  float4 v = make_float4(qnan, qnan, qnan, 0.f), n = v;
+  v = make_float4(qnan, qnan, qnan, 0.f), n = v;
   const int xs = 2 * x, ys = 2 * y;
   const float4 d00 = f4_at(vsrc, vsrc_pitch, ys + 0, xs + 0);
   const float4 d01 = f4_at(vsrc, vsrc_pitch, ys + 0, xs + 1);
@@ -200,8 +194,65 @@ __global__ __launch_bounds__(256) void resize_points_normals_kernel(const uint8_
     n = make_float4((n00.x + n01.x + n10.x + n11.x) * 0.25f, (n00.y + n01.y + n10.y + n11.y) * 0.25f,
                     (n00.z + n01.z + n10.z + n11.z) * 0.25f, 0.f);
   }
+}
+
+__global__ __launch_bounds__(256) void resize_points_normals_kernel(const uint8_t* vsrc, uint32_t vsrc_pitch,
+                                                                    const uint8_t* nsrc, uint32_t nsrc_pitch,
+                                                                    uint8_t* vdst, uint32_t vdst_pitch, uint8_t* ndst,
+                                                                    uint32_t ndst_pitch, int rows, int cols)
+{
+  const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+  const int y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+  if (x >= cols || y >= rows)
+    return;
+  float4 v, n;
+  resize_pixel(vsrc, vsrc_pitch, nsrc, nsrc_pitch, y, x, v, n);
   ((float4*)(vdst + (size_t)y * vdst_pitch))[x] = v;
   ((float4*)(ndst + (size_t)y * ndst_pitch))[x] = n;
+}
+
+// Two pyramid levels in one launch (the model maps after a ray cast: kinfu.cpp:294-306 calls resizePointsNormals
+// level by level; here the second call's launch and the gap in front of it are saved): a lane owns one pixel of the
+// quarter-size maps, computes the 2 x 2 half-size pixels under it as resize_pixel does, stores them, and
+// averages them again -- the arithmetic of the second call on the values of the first, so both levels are bit for
+// bit those of two calls.  Half-size pixels that no quarter-size pixel covers (odd half-size dimensions) are
+// computed by the lanes just beyond the quarter-size image.
+__global__ __launch_bounds__(256) void resize_points_normals2_kernel(const uint8_t* vsrc, uint32_t vsrc_pitch, const uint8_t* nsrc,
+                                                                     uint32_t nsrc_pitch, uint8_t* v1, uint32_t v1_pitch,
+                                                                     uint8_t* n1, uint32_t n1_pitch, int rows1, int cols1,
+                                                                     uint8_t* v2, uint32_t v2_pitch, uint8_t* n2,
+                                                                     uint32_t n2_pitch, int rows2, int cols2)
+{
+  const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
+  const int y = (int)(blockIdx.y * 4u + (threadIdx.x >> 6));
+  float4 v[2][2], n[2][2];
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx)
+    {
+      const int y1 = 2 * y + dy, x1 = 2 * x + dx;
+      if (y1 < rows1 && x1 < cols1)
+      {
+        resize_pixel(vsrc, vsrc_pitch, nsrc, nsrc_pitch, y1, x1, v[dy][dx], n[dy][dx]);
+        ((float4*)(v1 + (size_t)y1 * v1_pitch))[x1] = v[dy][dx];
+        ((float4*)(n1 + (size_t)y1 * n1_pitch))[x1] = n[dy][dx];
+      }
+    }
+  if (x >= cols2 || y >= rows2)
+    return;
+  const float qnan = __builtin_nanf("");
+  float4 vo = make_float4(qnan, qnan, qnan, 0.f), no = vo;
+  const float prod = v[0][0].x * v[0][1].x * v[1][0].x * v[1][1].x;
+  if (!(prod != prod))
+  {
+    vo = make_float4((v[0][0].x + v[0][1].x + v[1][0].x + v[1][1].x) * 0.25f, (v[0][0].y + v[0][1].y + v[1][0].y + v[1][1].y) * 0.25f,
+                     (v[0][0].z + v[0][1].z + v[1][0].z + v[1][1].z) * 0.25f, 0.f);
+    no = make_float4((n[0][0].x + n[0][1].x + n[1][0].x + n[1][1].x) * 0.25f, (n[0][0].y + n[0][1].y + n[1][0].y + n[1][1].y) * 0.25f,
+                     (n[0][0].z + n[0][1].z + n[1][0].z + n[1][1].z) * 0.25f, 0.f);
+  }
+  ((float4*)(v2 + (size_t)y * v2_pitch))[x] = vo;
+  ((float4*)(n2 + (size_t)y * n2_pitch))[x] = no;
 }
 
 // ---- debug display: imgproc.cu:400-561 ----
@@ -355,6 +406,19 @@ int launch_resize_points_normals(const yakhip_ctx* ctx, const uint8_t* points, s
                      (uint32_t)points_pitch, normals, (uint32_t)normals_pitch, points_out, (uint32_t)points_out_pitch,
                      normals_out, (uint32_t)normals_out_pitch, rows, cols);
   return check(hipGetLastError(), "resize_points_normals_kernel launch");
+}
+
+int launch_resize_points_normals2(const yakhip_ctx* ctx, const uint8_t* points, size_t points_pitch, const uint8_t* normals,
+                                  size_t normals_pitch, int src_rows, int src_cols, uint8_t* points1, size_t points1_pitch,
+                                  uint8_t* normals1, size_t normals1_pitch, uint8_t* points2, size_t points2_pitch,
+                                  uint8_t* normals2, size_t normals2_pitch)
+{
+  const int rows1 = src_rows / 2, cols1 = src_cols / 2, rows2 = rows1 / 2, cols2 = cols1 / 2;  // imgproc.cu:386-387, twice
+  hipLaunchKernelGGL(resize_points_normals2_kernel, image_grid((rows1 + 1) / 2, (cols1 + 1) / 2), dim3(256), 0, ctx->stream, points,
+                     (uint32_t)points_pitch, normals, (uint32_t)normals_pitch, points1, (uint32_t)points1_pitch, normals1,
+                     (uint32_t)normals1_pitch, rows1, cols1, points2, (uint32_t)points2_pitch, normals2,
+                     (uint32_t)normals2_pitch, rows2, cols2);
+  return check(hipGetLastError(), "resize_points_normals2_kernel launch");
 }
 
 int launch_render_image(const yakhip_ctx* ctx, bool from_depth, const uint8_t* src, size_t src_pitch, const uint8_t* normals,

@@ -214,6 +214,10 @@ int launch_depth_pyramid(const yakhip_ctx* ctx, const uint8_t* src, size_t src_p
                          uint8_t* dst, size_t dst_pitch, float sigma_depth);
 int launch_points_normals(const yakhip_ctx* ctx, const float intr[4], const uint8_t* depth, size_t depth_pitch, int rows,
                           int cols, uint8_t* points, size_t points_pitch, uint8_t* normals, size_t normals_pitch);
+int launch_resize_points_normals2(const yakhip_ctx* ctx, const uint8_t* points, size_t points_pitch, const uint8_t* normals,
+                                  size_t normals_pitch, int src_rows, int src_cols, uint8_t* points1, size_t points1_pitch,
+                                  uint8_t* normals1, size_t normals1_pitch, uint8_t* points2, size_t points2_pitch,
+                                  uint8_t* normals2, size_t normals2_pitch);
 int launch_resize_points_normals(const yakhip_ctx* ctx, const uint8_t* points, size_t points_pitch,
                                  const uint8_t* normals, size_t normals_pitch, int src_rows, int src_cols,
                                  uint8_t* points_out, size_t points_out_pitch, uint8_t* normals_out,

@@ -432,6 +432,18 @@ void resizePointsNormals(const Cloud& points, const Normals& normals, Cloud& poi
                                          points.rows(), points.cols(), points_out.ptr(), points_out.step(),
                                          normals_out.ptr(), normals_out.step()));
 }
+void resizePointsNormals2(const Cloud& points, const Normals& normals, Cloud& points_half, Normals& normals_half,
+                          Cloud& points_quarter, Normals& normals_quarter)
+{
+  points_half.create(points.rows() / 2, points.cols() / 2);
+  normals_half.create(normals.rows() / 2, normals.cols() / 2);
+  points_quarter.create(points.rows() / 2 / 2, points.cols() / 2 / 2);
+  normals_quarter.create(normals.rows() / 2 / 2, normals.cols() / 2 / 2);
+  YAK_CHECK(yakhip_resize_points_normals2(context(), points.ptr(), points.step(), normals.ptr(), normals.step(), points.rows(),
+                                          points.cols(), points_half.ptr(), points_half.step(), normals_half.ptr(),
+                                          normals_half.step(), points_quarter.ptr(), points_quarter.step(),
+                                          normals_quarter.ptr(), normals_quarter.step()));
+}
 void waitAllDefaultStream() { YAK_CHECK(yakhip_ctx_synchronize(context())); }  // imgproc.cpp:21
 
 void renderImage(const Depth& depth, const Normals& normals, const Intr& intr, const Vec3f& light_pose, Image& image)

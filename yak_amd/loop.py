@@ -143,10 +143,10 @@ def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None, on_system=No
         else:
             ctx.raycast_points(desc, np.float32(pose_R).reshape(-1), np.float32(pose_t), np.float32(Rv).reshape(-1), intr,
                                prv_p[0].data_ptr(), cols * 16, prv_n[0].data_ptr(), cols * 16, rows, cols)
-            for l in range(1, LEVELS):
-                ctx.resize_points_normals(prv_p[l - 1].data_ptr(), (cols >> (l - 1)) * 16, prv_n[l - 1].data_ptr(),
-                                          (cols >> (l - 1)) * 16, rows >> (l - 1), cols >> (l - 1), prv_p[l].data_ptr(),
-                                          (cols >> l) * 16, prv_n[l].data_ptr(), (cols >> l) * 16)
+            assert LEVELS == 3
+            ctx.resize_points_normals2(prv_p[0].data_ptr(), cols * 16, prv_n[0].data_ptr(), cols * 16, rows, cols,
+                                       prv_p[1].data_ptr(), (cols >> 1) * 16, prv_n[1].data_ptr(), (cols >> 1) * 16,
+                                       prv_p[2].data_ptr(), (cols >> 2) * 16, prv_n[2].data_ptr(), (cols >> 2) * 16)
         e[4].record()
         tR, tt = c2v(scene[f][1], scene[f][2])
         worst = max(worst, float(np.linalg.norm(pose_t - tt)))
