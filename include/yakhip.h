@@ -74,7 +74,7 @@ typedef struct yakhip_volume
  *   yakhip_integrate / _static / _batch   set the bits of the bricks in which a negative measurement was folded
  *                                         into a voxel (nothing else can make a voxel negative);
  *   yakhip_clear_volume                   clears the map with the voxels;
- *   yakhip_raycast_* (and _slab/_sharded) and yakhip_marching_cubes[_layers] consult it;
+ *   yakhip_raycast_* (and _slab/_sharded), yakhip_marching_cubes[_layers] and yakhip_extract_cloud consult it;
  *   yakhip_surface_map_rebuild            recomputes it from the voxels.
  * The map belongs to one (data, z0, z1): pass the same three with it every time.  Whoever writes voxels by other
  * means (an upload, a copy, a kernel of his own) calls yakhip_surface_map_rebuild before the next ray cast, or

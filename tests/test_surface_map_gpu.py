@@ -299,7 +299,7 @@ def test_raycast_512_with_the_map_on_a_volume_fused_on_the_gpu(gpu_ctx):
         assert same_bits(raycast(gpu_ctx, s.desc, R, t, R_v2c, synth.INTR, rows, cols), plain)
 
 
-def test_marching_cubes_with_the_map_gives_the_same_triangles(gpu_ctx):
+def test_marching_cubes_and_cloud_with_the_map_give_the_same_output(gpu_ctx):
     """The count pass leaves out what no marked brick is near; the triangle list is the same, entry for entry --
     whole slab, a slab that starts inside the volume, and a layer range of a slab (yakhip_marching_cubes_layers)."""
     for dims, z0, z1 in [((128, 128, 128), 0, None), ((72, 40, 100), 0, None), ((96, 96, 160), 37, 121)]:
@@ -328,6 +328,18 @@ def test_marching_cubes_with_the_map_gives_the_same_triangles(gpu_ctx):
         assert len(want) > 300
         for desc in (s.desc, s.plain):
             assert np.array_equal(mesh(gpu_ctx.marching_cubes_layers, desc, a, b).view(np.uint32), want.view(np.uint32))
+        # the cloud extraction's count pass does the same (yakhip_extract_cloud)
+        pose_R, pose_t = np.eye(3, dtype=np.float32).reshape(-1), np.zeros(3, dtype=np.float32)
+
+        def cloud(desc):
+            n = gpu_ctx.extract_cloud(desc, pose_R, pose_t)
+            pts = torch.full((max(n, 1), 4), 7.0, dtype=torch.float32, device="cuda")
+            assert gpu_ctx.extract_cloud(desc, pose_R, pose_t, pts.data_ptr(), n) == n
+            return pts.cpu().numpy()[:n]
+
+        plain_cloud = cloud(s.plain)
+        assert len(plain_cloud) > 500
+        assert np.array_equal(cloud(s.desc).view(np.uint32), plain_cloud.view(np.uint32))
     with pytest.raises(capi.YakHipError):
         gpu_ctx.marching_cubes_layers(s.desc, s.z0 - 1, s.z1, 2, 1.0)
 

@@ -1097,7 +1097,8 @@ int yakhip_extract_cloud(yakhip_ctx* ctx, const yakhip_volume* vol, const float 
   if (points_dev && ((uintptr_t)points_dev & 15) != 0)
     return fail(YAKHIP_EALIGN, "extract_cloud: points buffer not 16-byte aligned");
   return launch_extract_cloud(ctx, (const uint32_t*)vol->data, vol->dims[0], vol->dims[1], vol->z0, vol->z1 - vol->z0,
-                              vol->voxel_size, R, t, (float*)points_dev, capacity_points, n_points_host);
+                              vol->voxel_size, R, t, (float*)points_dev, capacity_points, n_points_host,
+                              (const uint32_t*)vol->surface_map);
 }
 
 int yakhip_extract_normals(yakhip_ctx* ctx, const yakhip_volume* vol, const void* points_dev, unsigned long long n_points,

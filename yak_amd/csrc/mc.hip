@@ -461,6 +461,9 @@ struct CloudParams
   float vsx, vsy, vsz;
   float R[9], t[3];
   unsigned long long capacity;
+  // surface map of the slab (yakhip_volume.surface_map) or nullptr, as in McParams; vol's first layer is the map's
+  const uint32_t* map;
+  int map_x, map_y;
 };
 
 // "W != 0 && F != 1.f" (tsdf_volume.cu:524, 535, ...) and the value
@@ -488,6 +491,30 @@ __global__ __launch_bounds__(256) void cloud_kernel(const CloudParams p, uint32_
   const int walk = EMIT ? p.z_sub : p.z_chunk;
   const size_t tile_stride = (size_t)p.ny * p.nx;
   size_t tile = ((size_t)zc * (size_t)(walk / p.z_sub) * p.ny + yt) * p.nx + xt;
+  if (!EMIT && p.map)
+  {
+    // A point needs a pair of voxels of opposite strict sign, one of them negative, and a brick whose bit is clear
+    // holds no negative voxel: if none of the bricks this wave's voxels lie in (owners and their +x, +y, +z
+    // neighbours) is marked, its tiles are empty and nothing is read (as in mc_kernel).
+    const int vx0 = xt * kRun, vx1 = min(vx0 + kRun, p.X - 1), vy0 = yt * kRows, vy1 = min(vy0 + kRows, p.Y - 1);
+    const int vz0 = zc * walk, vz1 = min(vz0 + walk, p.pair_layers);  // pair layer z uses layers z and z + 1
+    const int bx0 = vx0 >> 4, nbx = (vx1 >> 4) - bx0 + 1, by0 = vy0 >> 4, nby = (vy1 >> 4) - by0 + 1;
+    const int bz0 = vz0 >> 4, nbz = (vz1 >> 4) - bz0 + 1;
+    bool marked = false;
+    for (int i = lane; i < nbx * nby * nbz; i += 64)
+    {
+      const int ix = i % nbx, iy = (i / nbx) % nby, iz = i / (nbx * nby);
+      const uint32_t b = (uint32_t)(bx0 + ix) + (uint32_t)p.map_x * ((uint32_t)(by0 + iy) + (uint32_t)p.map_y * (uint32_t)(bz0 + iz));
+      marked = marked || ((p.map[b >> 5] >> (b & 31u)) & 1u);
+    }
+    if (__builtin_amdgcn_ballot_w64(marked) == 0)
+    {
+      const int n_sub = (vz1 - vz0 + p.z_sub - 1) / p.z_sub;
+      if (lane < n_sub)
+        counts[tile + (size_t)lane * tile_stride] = 0;
+      return;
+    }
+  }
   unsigned long long out = 0;
   if (EMIT)
   {
@@ -726,7 +753,7 @@ static int tile_scratch(yakhip_ctx* ctx, size_t n_tiles, uint32_t** counts, uint
 
 int launch_extract_cloud(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int z0, int layers, const float vs[3],
                          const float R[9], const float t[3], float* points, unsigned long long capacity,
-                         unsigned long long* n_out)
+                         unsigned long long* n_out, const uint32_t* map)
 {
   *n_out = 0;
   if (layers < 2)
@@ -749,6 +776,8 @@ int launch_extract_cloud(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int
   for (int i = 0; i < 3; ++i)
     p.t[i] = t[i];
   p.capacity = points ? capacity : 0;
+  p.map = ctx->surface_skip ? map : nullptr;
+  p.map_x = (X + 15) >> 4, p.map_y = (Y + 15) >> 4;
   const unsigned gy = (unsigned)((p.ny + 3) / 4);
   const size_t n_tiles = (size_t)p.nx * p.ny * p.nzs, wgs_layer = (size_t)p.nx * gy;
   if (wgs_layer * (size_t)p.nzs > 0x7fffffffull)

@@ -246,7 +246,7 @@ int launch_marching_cubes(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, in
 // (map: the surface map of the slab these layers are part of, whose layer map_z0 is `vol`'s first; nullptr: read everything)
 int launch_extract_cloud(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int z0, int layers, const float vs[3],
                          const float R[9], const float t[3], float* points, unsigned long long capacity,
-                         unsigned long long* n_out);
+                         unsigned long long* n_out, const uint32_t* map = nullptr);
 
 // icp.hip: the device-resident schedule.  status_out: 0 = done, 2 = some system needs the host path.
 int launch_icp_estimate(yakhip_ctx* ctx, const float R[9], const float t[3], const float intr[4], float dist_thres,
