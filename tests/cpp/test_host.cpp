@@ -293,6 +293,38 @@ static void test_fusion_server_against_oracle()
   const yak::TSDFContainer back = server.downloadTSDF();
   EXPECT(back.size64() == saved.size64() && std::memcmp(back.data(), saved.data(), saved.size64() * 4) == 0);
   EXPECT(!server.uploadTSDF(yak::TSDFContainer(8, 8, 8)));
+  // A volume written behind the class's back (the non-const data() handle marks its surface map stale): fetchCloud --
+  // a const member, it cannot recompute the map -- must read the voxels, not trust the map of the empty volume.
+  {
+    probe.tsdf().data().upload(saved.data(), saved.size64() * sizeof(std::uint32_t));
+    kfusion::cuda::DeviceArray<kfusion::Point> buffer;
+    const kfusion::cuda::TsdfVolume& tv = probe.tsdf();
+    const std::size_t got = tv.fetchCloud(buffer).size();
+    // tsdf_volume.cu:524-612: a point per voxel pair (x, y, z) / +x, +y, +z with weights != 0, tsdf != 1, opposite strict signs
+    const int X = 64, Y = 48, Z = 56;
+    std::size_t pairs = 0;
+    auto at = [&](int x, int y, int z, float& F) {
+      std::uint16_t h, w;
+      const std::size_t i = (std::size_t)x + (std::size_t)X * ((std::size_t)y + (std::size_t)Y * (std::size_t)z);
+      saved.read(i, h, w);
+      F = saved.distance(i);
+      return w != 0 && F != 1.f;
+    };
+    for (int z = 0; z < Z - 1; ++z)
+      for (int y = 0; y < Y; ++y)
+        for (int x = 0; x < X; ++x)
+        {
+          float F, Fn;
+          if (!at(x, y, z, F))
+            continue;
+          const int nb[3][3] = { { x + 1, y, z }, { x, y + 1, z }, { x, y, z + 1 } };
+          for (const auto& n : nb)
+            if (n[0] < X && n[1] < Y && at(n[0], n[1], n[2], Fn))
+              pairs += (F > 0.f && Fn < 0.f) || (F < 0.f && Fn > 0.f);
+        }
+    std::printf("  cloud of the uploaded volume: %zu points, %zu sign changes in the container\n", got, pairs);
+    EXPECT(pairs > 100 && got == pairs);
+  }
   // DeviceMemory::copyTo is a device-to-device copy into memory of its own
   kfusion::cuda::CudaData copy;
   probe.tsdf().data().copyTo(copy);

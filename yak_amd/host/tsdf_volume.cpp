@@ -372,7 +372,9 @@ DeviceArray<Point> TsdfVolume::fetchCloud(DeviceArray<Point>& cloud_buffer) cons
 
   const Mat3f R = pose_.rotation();
   const Vec3f t = pose_.translation();
-  const yakhip_volume v = view();
+  yakhip_volume v = view();
+  if (map_stale_)
+    v.surface_map = nullptr;  // (const: the map is not recomputed here, the extraction reads every voxel instead)
   unsigned long long n = 0;
   YAK_CHECK(yakhip_extract_cloud(context(), &v, R.val, t.val, cloud_buffer.ptr(), cloud_buffer.size(), &n));
   const size_t size = n < cloud_buffer.size() ? (size_t)n : cloud_buffer.size();
