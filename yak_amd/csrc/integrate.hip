@@ -748,12 +748,16 @@ enum BrickClass
   kBrickFront = 2
 };
 
-template <int VX>
+// GROUP = 64: the calling wave settles its own brick, all lanes sharing the work.  GROUP = 8: every group of eight
+// lanes of the calling wave settles the brick of wave (lane / 8) of the workgroup (groups 4..7 repeat 0..3), so one
+// wave does the test for all four -- a quarter of the instructions, and on an orbit frame, where 82 % of the waves
+// are dead, the test is a sixth of all the kernel issues.  Returns the class of the lane's group.
+template <int VX, int GROUP>
 __device__ __forceinline__ int classify_brick(const IntegrateParams& p, int zs, int ze)
 {
-  // voxel index ranges of this WAVE (see lane_voxels)
+  // voxel index ranges of the WAVE in question (see lane_voxels)
   int xlo, xhi, ylo, yhi;
-  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t wave = GROUP == 64 ? threadIdx.x >> 6 : (threadIdx.x >> 3) & 3u;
   if (p.tile_shift >= 6)
   {
     const uint32_t e0 = (blockIdx.x * 4u + wave) * (64u * VX);
@@ -842,7 +846,7 @@ __device__ __forceinline__ int classify_brick(const IntegrateParams& p, int zs, 
       if (n <= 256)
       {
         float amin = __builtin_inff(), bmax = -__builtin_inff();
-        for (int i = (int)lane; i < n; i += 64)
+        for (int i = (int)(lane & (GROUP - 1)); i < n; i += GROUP)
         {
           const int yy = i / ncx, xx = i - yy * ncx;
           const int idx = (cy0 + yy) * p.ccw + cx0 + xx;
@@ -850,7 +854,7 @@ __device__ __forceinline__ int classify_brick(const IntegrateParams& p, int zs, 
           bmax = __builtin_fmaxf(bmax, p.cellmax[idx]);
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
+        for (int off = GROUP / 2; off > 0; off >>= 1)
         {
           amin = __builtin_fminf(amin, __shfl_xor(amin, off));
           bmax = __builtin_fmaxf(bmax, __shfl_xor(bmax, off));
@@ -867,7 +871,10 @@ __device__ __forceinline__ int classify_brick(const IntegrateParams& p, int zs, 
       }
     }
   }
-  return __builtin_amdgcn_readfirstlane(cls);
+  if constexpr (GROUP == 64)
+    return __builtin_amdgcn_readfirstlane(cls);
+  else
+    return cls;
 }
 
 // A "front" brick: every voxel of the chunk takes the measurement 1.0.  Plain streaming: two layers in flight.
@@ -904,9 +911,40 @@ __device__ __forceinline__ void walk_front(const IntegrateParams& p, rsrc_t rs, 
 // VX voxels per lane along x.  The z loop is software-pipelined two layers deep with two register
 // sets (A, B): while layer z is being settled and written, layer z+1 is already tested/projected
 // (its threshold gathers in flight), and the voxels of layers z+1 / z+2 are being fetched.
+#ifdef YAK_INTEGRATE_TIMING
+// diagnostic build only (make EXTRA=-DYAK_INTEGRATE_TIMING; tools/bench_orbit_waves.py): per wave of the last launch
+// {class + 1, shader-clock cycles in all, cycles to the end of the brick test, replay cycles,
+//  layers walked | duration in 10 ns ticks << 16, HW_ID << 40 | start on the device-wide 100 MHz clock}
+constexpr int kItSlots = 1 << 17;
+__device__ unsigned long long g_it_time[kItSlots][6];
+#define IT_CLOCK(var) var = __builtin_readcyclecounter()
+#define IT_ROW(cls_, t_cls_, t_replay_, layers_)                                                                          \
+  do                                                                                                                     \
+  {                                                                                                                      \
+    if ((threadIdx.x & 63u) == 0)                                                                                        \
+    {                                                                                                                    \
+      unsigned hw;                                                                                                       \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                                   \
+      unsigned long long* row =                                                                                          \
+          g_it_time[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) & (kItSlots - 1)];          \
+      const unsigned long long it_now = __builtin_readcyclecounter();                                                    \
+      row[0] = (unsigned long long)(cls_) + 1, row[1] = it_now - it_t0, row[2] = (t_cls_) - it_t0, row[3] = (t_replay_); \
+      row[4] = (unsigned long long)(layers_) | ((__builtin_amdgcn_s_memrealtime() - it_r0) << 16);                       \
+      row[5] = ((unsigned long long)hw << 40) | (it_r0 & 0xffffffffffull);                                               \
+    }                                                                                                                    \
+  } while (0)
+#else
+#define IT_CLOCK(var)
+#define IT_ROW(cls_, t_cls_, t_replay_, layers_)
+#endif
 template <int VX, bool NT>
 __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams p, const ChunkTable chunks)
 {
+#ifdef YAK_INTEGRATE_TIMING
+  unsigned long long it_t0, it_t1 = 0, it_t2 = 0, it_t3 = 0;
+  const unsigned long long it_r0 = __builtin_amdgcn_s_memrealtime();
+  IT_CLOCK(it_t0);
+#endif
   typedef typename Vec<VX>::type vec_t;
   extern __shared__ __attribute__((aligned(16))) float coarse_lds[];
 
@@ -915,22 +953,27 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
   const int zs = p.z0 + __builtin_amdgcn_readfirstlane((int)chunks.first[blockIdx.y]);
   const int ze = zs + __builtin_amdgcn_readfirstlane((int)chunks.layers[blockIdx.y]);
 
-  // brick test: wave-uniform class of this wave's brick
-  const int cls = p.brick_enable ? classify_brick<VX>(p, zs, ze) : kBrickMixed;
-  if (p.brick_stats && (threadIdx.x & 63u) == 0)  // measurement aid, off by default
-    atomicAdd(&p.brick_stats[cls], 1u);
-
-  // The coarse threshold image (a few KiB, read once per workgroup into LDS) is only needed by mixed bricks; the
-  // waves of the workgroup agree on it through LDS.
-  __shared__ int wave_mixed[4];
+  // brick test: the class of every wave's brick, settled by the first wave for all four (eight lanes per brick) and
+  // handed over through LDS
+  __shared__ int wave_class[4];
+  int cls = kBrickMixed;
   bool fill = VX == 4 && p.grp_enable;
   if (p.brick_enable)
   {
-    if ((threadIdx.x & 63u) == 0)
-      wave_mixed[threadIdx.x >> 6] = cls == kBrickMixed;
+    if (threadIdx.x < 64u)
+    {
+      const int c = classify_brick<VX, 8>(p, zs, ze);
+      if (threadIdx.x < 32u && (threadIdx.x & 7u) == 0)
+        wave_class[threadIdx.x >> 3] = c;
+    }
     __syncthreads();
-    fill = fill && (wave_mixed[0] || wave_mixed[1] || wave_mixed[2] || wave_mixed[3]);
+    cls = __builtin_amdgcn_readfirstlane(wave_class[threadIdx.x >> 6]);
+    // The coarse threshold image (a few KiB, read once per workgroup into LDS) is only needed by mixed bricks.
+    fill = fill && (wave_class[0] == kBrickMixed || wave_class[1] == kBrickMixed || wave_class[2] == kBrickMixed ||
+                    wave_class[3] == kBrickMixed);
   }
+  if (p.brick_stats && (threadIdx.x & 63u) == 0)  // measurement aid, off by default
+    atomicAdd(&p.brick_stats[cls], 1u);
   if (fill)
   {
     const int n = p.cw * p.ch;
@@ -938,8 +981,12 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
       coarse_lds[i] = p.coarse[i];
     __syncthreads();
   }
+  IT_CLOCK(it_t1);
   if (cls == kBrickDead)
+  {
+    IT_ROW(cls, it_t1, 0, 0);
     return;
+  }
 
   uint32_t elem;  // x + y*X of the lane's first voxel; X % VX == 0 so no row straddle
   int x0, y;
@@ -953,6 +1000,7 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
     const rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(p.vol + (size_t)(zs - p.z0) * p.plane, 0,
                                                          (uint32_t)(ze - zs) * lb, 0x00020000);
     walk_front<VX, NT>(p, rsf, elem * 4u, lb, ze - zs, active, ((uint32_t)p.max_weight << 16) | 0xffffu);
+    IT_ROW(cls, it_t1, 0, ze - zs);
     return;
   }
   const int ws = zs, we = ze;  // the layers walked voxel by voxel
@@ -995,8 +1043,10 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
       }
     replay = ws - p.z0;
   }
+  IT_CLOCK(it_t2);
   for (int i = 0; i < replay; ++i)
     advance<VX>(A, A, sx, sy, sz);
+  IT_CLOCK(it_t3);
 
   const f32x2 fx2 = { p.fx, p.fx }, fy2 = { p.fy, p.fy }, cx2 = { p.cx, p.cx }, cy2 = { p.cy, p.cy };
   const uint32_t max_w_hi = ((uint32_t)p.max_weight << 16) | 0xffffu;
@@ -1039,7 +1089,20 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
   }
   if (p.bricks)
     mark_cells(p, marked, x0, y, ws - p.z0, we - p.z0);
+  IT_ROW(cls, it_t1, it_t3 - it_t2, we - ws);
 }
+#ifdef YAK_INTEGRATE_TIMING
+extern "C" int yakhip_debug_integrate_rows(unsigned long long* out, int max_rows)
+{
+  void* at = nullptr;
+  const int n = max_rows < kItSlots ? max_rows : kItSlots;
+  if (hipDeviceSynchronize() != hipSuccess || hipGetSymbolAddress(&at, HIP_SYMBOL(g_it_time)) != hipSuccess ||
+      hipMemcpy(out, at, (size_t)n * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemset(at, 0, (size_t)n * 6 * sizeof(unsigned long long)) != hipSuccess)
+    return -1;
+  return n;
+}
+#endif
 
 template <int VX>
 static int launch_variant(yakhip_ctx* ctx, const IntegrateParams& p, const ChunkTable& chunks, dim3 grid, bool use_static)
@@ -1436,7 +1499,7 @@ __global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchPara
 #pragma unroll
   for (int k = 0; k < K; ++k)
   {
-    cls[k] = p.brick_enable ? classify_brick<VX>(bp.f[k], zs, ze) : kBrickMixed;
+    cls[k] = p.brick_enable ? classify_brick<VX, 64>(bp.f[k], zs, ze) : kBrickMixed;
     any_mixed = any_mixed || cls[k] == kBrickMixed;
     all_dead = all_dead && cls[k] == kBrickDead;
   }
