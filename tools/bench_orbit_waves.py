@@ -56,6 +56,7 @@ def main():
         ctx.close()
         return
     got = rows_fn(out.ctypes.data, 1 << 17)
+    slots = np.nonzero(out[:got, 0] > 0)[0]
     r = out[:got][out[:got, 0] > 0].astype(np.int64)
     cls = r[:, 0] - 1                                                     # 0 mixed, 1 dead, 2 front
     total, to_cls, replay, layers = r[:, 1], r[:, 2], r[:, 3], r[:, 4] & 0xffff
@@ -95,6 +96,15 @@ def main():
     print("  mixed waves by start time (eighths of the launch):", hist.tolist())
     hist, edges = np.histogram((start[m] + real[m]) / 100.0, bins=8, range=(0, span / 100.0))
     print("  mixed waves by end time:", hist.tolist())
+    # per z-chunk, in dispatch order (blockIdx.y): rows are indexed ((chunk * blocks + block) * 4 + wave)
+    per_chunk = 4 * ((n * n // 4 + 255) // 256)
+    chunk = slots // per_chunk
+    print("  chunk (dispatch order): waves mixed / front / dead, mixed wave-time us, first start us, last end us")
+    for c in range(int(chunk.max()) + 1):
+        k = chunk == c
+        km = k & (cls == 0)
+        print("    %2d: %4d %4d %5d  %8.0f  %6.1f %6.1f  layers %d" % (c, km.sum(), (k & (cls == 2)).sum(), (k & (cls == 1)).sum(), real[km].sum() / 100.0,
+                                                   start[k].min() / 100.0, (start[k] + real[k]).max() / 100.0, layers[km].max() if km.any() else 0))
     busy_us = real[m].sum() / 100.0
     print("  mixed wave time in all: %.0f us = %.1f us per SIMD if spread over 1024" % (busy_us, busy_us / 1024))
     ctx.close()
