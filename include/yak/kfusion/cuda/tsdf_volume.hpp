@@ -55,6 +55,10 @@ public:
    *  keeps the ray-distance image alive until the work is done (KinFu does) may switch the wait off.  No counterpart
    *  in the reference. */
   void setBlockingIntegrate(bool blocking);
+  /** The part of integrate()'s work on `dists` that needs no pose, ahead of time and on the stream that is current
+   *  (include/yakhip.h, yakhip_integrate_prepare): the integrate() of the same image that follows launches the voxel
+   *  walk only.  Optional; the voxels come out the same.  No counterpart in the reference. */
+  void prepareIntegrate(const Dists& dists);
 
   // ---- z-slab sharding (no counterpart in the reference; world == 1 leaves everything above as it is) ----
   /** Layers [z0, z1) of the volume this object OWNS on the calling thread's rank (cuda::currentShard()). */

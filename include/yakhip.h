@@ -195,6 +195,15 @@ int yakhip_compute_dists(yakhip_ctx* ctx, const void* depth_dev, size_t depth_pi
  * position is accumulated from z = 0 exactly as tsdf_volume.cu:76 does). */
 int yakhip_integrate(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dists_dev, size_t dists_pitch, int rows,
                      int cols, const float R[9], const float t[3], const float intr[4]);
+/* Optional, no counterpart in the reference: the part of yakhip_integrate's work that does not depend on the pose
+ * (per-pixel band thresholds and the coarse planes its culling tests read), ahead of time and on whatever stream is
+ * current -- e.g. between yakhip_ctx_side_begin / _end, beside the previous frame's work.  The next yakhip_integrate
+ * call with the same image (pointer, pitch, size; untouched in between) and truncation distance then launches its
+ * walk only; any other integrate call in between discards what was prepared.  Two calls in a row use two scratch
+ * areas in turn, so frame f + 1 may be prepared while frame f is still being integrated.  Slabs that start from
+ * column checkpoints (z0 >= 64) take nothing from it.  Results are the same bit for bit. */
+int yakhip_integrate_prepare(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dists_dev, size_t dists_pitch, int rows,
+                             int cols);
 
 /* yakhip_integrate for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for code
  * under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments, same

@@ -1,0 +1,115 @@
+"""yakhip_integrate_prepare (no counterpart in the reference): the pose-independent prepass of a frame run ahead of
+time, on the side stream in the frame loop.  Whatever the order of calls, the voxels must come out bit for bit as
+yakhip_integrate alone writes them: a prepared frame is only taken up by the integrate call of the same image, and
+every other integrate call in between discards it.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from yak_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(rows, cols, seed, tilt):
+    rng = np.random.default_rng(seed)
+    v, u = np.mgrid[0:rows, 0:cols].astype(np.float32)
+    depth = (2200.0 + tilt * u - 0.7 * v + rng.normal(0.0, 2.0, (rows, cols))).astype(np.float32)
+    depth[rng.random((rows, cols)) < 0.05] = 0.0
+    depth = np.clip(depth, 0, 65535).astype(np.uint16)
+    intr = (0.9 * cols, 0.9 * cols, cols / 2 - 0.5, rows / 2 - 0.5)
+    return oracle.compute_dists(depth, intr), intr
+
+
+def _setup(dims, z0, z1, rows, cols):
+    voxel = 2.2 / (z0 + z1)
+    vs = (voxel, voxel, voxel)
+    tr = max(0.06, 2.1 * voxel)
+    a, intr = _frame(rows, cols, 7, 1.3)
+    b, _ = _frame(rows, cols, 8, -0.9)
+    R = np.eye(3, dtype=np.float32)
+    t = np.array([-dims[0] * voxel / 2, -dims[1] * voxel / 2, 1.2], dtype=np.float32)
+    da = torch.from_numpy(a.view(np.int16)).cuda()
+    db = torch.from_numpy(b.view(np.int16)).cuda()
+    return vs, tr, intr, R, t, da, db
+
+
+def _volume(dims, vs, tr, z0, z1):
+    vol = torch.zeros(dims[0] * dims[1] * (z1 - z0), dtype=torch.int32, device="cuda")
+    return vol, capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT, z0, z1)
+
+
+def _words(vol):
+    torch.cuda.synchronize()
+    return vol.cpu().numpy().view(np.uint32).copy()
+
+
+CASES = [
+    ((128, 96, 160), 0, 160, (480, 640)),
+    ((30, 22, 19), 0, 19, (37, 53)),         # 8-byte path, odd image
+    ((64, 64, 256), 128, 200, (240, 320)),   # deep slab: the prepass computes checkpoints from the pose, prepare does nothing
+]
+
+
+@pytest.mark.parametrize("dims,z0,z1,image", CASES)
+def test_prepared_frames_give_the_same_voxels(gpu_ctx, dims, z0, z1, image):
+    rows, cols = image
+    vs, tr, intr, R, t, da, db = _setup(dims, z0, z1, rows, cols)
+    args = lambda d: (d.data_ptr(), cols * 2, rows, cols, R.reshape(-1), t, intr)  # noqa: E731
+    pre = lambda desc, d: gpu_ctx.integrate_prepare(desc, d.data_ptr(), cols * 2, rows, cols)  # noqa: E731
+
+    vol, desc = _volume(dims, vs, tr, z0, z1)
+    for d in (da, db, da):
+        gpu_ctx.integrate(desc, *args(d))
+    want = _words(vol)
+    assert np.count_nonzero(want >> 16) > 0
+
+    # each frame prepared right before it is integrated
+    vol, desc = _volume(dims, vs, tr, z0, z1)
+    for d in (da, db, da):
+        pre(desc, d)
+        gpu_ctx.integrate(desc, *args(d))
+    assert np.array_equal(_words(vol), want)
+
+    # the next frame prepared before the current one is integrated (two scratch areas in turn), on the side stream
+    vol, desc = _volume(dims, vs, tr, z0, z1)
+    seq = (da, db, da)
+    gpu_ctx.side_begin()
+    pre(desc, seq[0])
+    gpu_ctx.side_end()
+    for k, d in enumerate(seq):
+        gpu_ctx.integrate(desc, *args(d))
+        if k + 1 < len(seq):
+            gpu_ctx.side_begin()
+            pre(desc, seq[k + 1])
+            gpu_ctx.side_end()
+    assert np.array_equal(_words(vol), want)
+
+    # a prepared frame that is not the one integrated next is discarded, also by the other entry points
+    vol, desc = _volume(dims, vs, tr, z0, z1)
+    pre(desc, db)
+    gpu_ctx.integrate(desc, *args(da))       # another image: own prepass
+    pre(desc, da)
+    pre(desc, db)                            # replaces the record of da
+    gpu_ctx.integrate_static(desc, *args(db))  # static scratch: takes nothing from it
+    pre(desc, db)
+    gpu_ctx.integrate_batch(desc, [args(da)])
+    assert np.array_equal(_words(vol), want)
+
+
+def test_prepare_after_a_smaller_frame_grows_the_scratch(gpu_ctx):
+    dims, z0, z1 = (64, 48, 40), 0, 40
+    vs, tr, intr_s, R, t, sa, _ = _setup(dims, z0, z1, 60, 80)
+    _, _, intr_l, _, _, la, _ = _setup(dims, z0, z1, 240, 320)
+    vol, desc = _volume(dims, vs, tr, z0, z1)
+    gpu_ctx.integrate(desc, sa.data_ptr(), 160, 60, 80, R.reshape(-1), t, intr_s)
+    gpu_ctx.integrate(desc, la.data_ptr(), 640, 240, 320, R.reshape(-1), t, intr_l)
+    want = _words(vol)
+    vol, desc = _volume(dims, vs, tr, z0, z1)
+    gpu_ctx.integrate_prepare(desc, sa.data_ptr(), 160, 60, 80)
+    gpu_ctx.integrate(desc, sa.data_ptr(), 160, 60, 80, R.reshape(-1), t, intr_s)
+    gpu_ctx.integrate_prepare(desc, la.data_ptr(), 640, 240, 320)  # larger image: the scratch is replaced
+    gpu_ctx.integrate(desc, la.data_ptr(), 640, 240, 320, R.reshape(-1), t, intr_l)
+    assert np.array_equal(_words(vol), want)

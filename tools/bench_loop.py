@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--no-icp", action="store_true")
     ap.add_argument("--host-icp", action="store_true", help="one blocking linearisation at a time, numpy solve")
     ap.add_argument("--no-overlap", action="store_true", help="pre-processing on the main stream, behind the frame before")
+    ap.add_argument("--no-prepare", action="store_true", help="the integrate prepass stays on the main stream")
     ap.add_argument("--no-poll", action="store_true", help="yakhip_icp_estimate copies and synchronises instead of polling")
     args = ap.parse_args()
     from yak_amd import capi
@@ -25,9 +26,9 @@ def main():
     ctx = capi.Context(0)
     if args.no_poll:
         ctx.set_option("icp_poll", 0)
-    run_kinfu_loop(ctx, args.n, 8, "device", overlap=not args.no_overlap)  # warm-up
+    run_kinfu_loop(ctx, args.n, 8, "device", overlap=not args.no_overlap, prepare=not args.no_prepare)  # warm-up
     mode = None if args.no_icp else ("host" if args.host_icp else "device")
-    r = run_kinfu_loop(ctx, args.n, args.frames, mode, overlap=not args.no_overlap)
+    r = run_kinfu_loop(ctx, args.n, args.frames, mode, overlap=not args.no_overlap, prepare=not args.no_prepare)
     print("%d^3, %d frames of the S2 orbit, ICP %s: %.1f frames/s (wall %.3f s); worst position error %.1f mm" % (
         r["n"], r["frames"], {None: "off (true poses)", "host": "on (host loop)", "device": "on (device loop)"}[mode],
         r["frames_per_s"], r["wall_s"], r["worst_position_error_mm"]))

@@ -20,7 +20,7 @@ EXPORTS = [
     "yakhip_integrate_batch",
     "yakhip_raycast_points", "yakhip_raycast_depth", "yakhip_raycast_slab", "yakhip_raycast_resolve", "yakhip_raycast_halo",
     "yakhip_bilateral_filter", "yakhip_truncate_depth", "yakhip_depth_pyramid", "yakhip_compute_points_normals",
-    "yakhip_resize_points_normals", "yakhip_resize_points_normals2", "yakhip_icp_accumulate", "yakhip_icp_accumulate_rows", "yakhip_icp_estimate",
+    "yakhip_integrate_prepare", "yakhip_resize_points_normals", "yakhip_resize_points_normals2", "yakhip_icp_accumulate", "yakhip_icp_accumulate_rows", "yakhip_icp_estimate",
     "yakhip_marching_cubes", "yakhip_marching_cubes_layers", "yakhip_weld_vertices", "yakhip_extract_cloud", "yakhip_extract_normals",
     "yakhip_render_image_points", "yakhip_render_image_depth", "yakhip_render_tangent_colors",
     "yakhip_comm_unique_id", "yakhip_comm_create_rccl", "yakhip_comm_create_local", "yakhip_comm_create_custom",
@@ -120,6 +120,7 @@ def load():
         "yakhip_compute_dists": [vp, vp, sz, vp, sz, i, i, fp],
         "yakhip_integrate": [vp, volp, vp, sz, i, i, fp, fp, fp],
         "yakhip_integrate_static": [vp, volp, vp, sz, i, i, fp, fp, fp],
+        "yakhip_integrate_prepare": [vp, volp, vp, sz, i, i],
         "yakhip_integrate_batch": [vp, volp, C.POINTER(FrameDesc), i],
         "yakhip_raycast_points": [vp, volp, fp, fp, fp, fp, C.c_float, C.c_float, vp, sz, vp, sz, i, i],
         "yakhip_raycast_depth": [vp, volp, fp, fp, fp, fp, C.c_float, C.c_float, vp, sz, vp, sz, i, i],
@@ -274,6 +275,10 @@ class Context:
     def integrate(self, vol, dists_ptr, dists_pitch, rows, cols, R, t, intr):
         _chk(load().yakhip_integrate(self._h, C.byref(vol), C.c_void_p(dists_ptr), dists_pitch, rows, cols,
                                      _f32(R, 9), _f32(t, 3), _f32(intr, 4)))
+
+    def integrate_prepare(self, vol, dists_ptr, dists_pitch, rows, cols):
+        """The pose-independent part of integrate(), ahead of time on the current stream (include/yakhip.h)."""
+        _chk(load().yakhip_integrate_prepare(self._h, C.byref(vol), C.c_void_p(dists_ptr), dists_pitch, rows, cols))
 
     def integrate_static(self, vol, dists_ptr, dists_pitch, rows, cols, R, t, intr):
         """yakhip_integrate without any allocation in the call (scratch in the library's file-scope array)."""

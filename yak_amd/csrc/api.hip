@@ -152,6 +152,8 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->icp_pinned = nullptr;
   ctx->icp_ticket = 0;
   ctx->icp_poll = 1;
+  ctx->prepared.valid = false;
+  ctx->prepared_next = 0;
   ctx->mc_scratch = nullptr;
   ctx->mc_scratch_bytes = 0;
   ctx->mc_pinned = nullptr;
@@ -858,6 +860,21 @@ int yakhip_integrate(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dist
   if ((rc = fill_integrate_params(p, vol, dists_dev, dists_pitch, rows, cols, R, t, intr)) != 0)
     return rc;
   return launch_integrate(ctx, p);
+}
+
+int yakhip_integrate_prepare(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dists_dev, size_t dists_pitch, int rows,
+                             int cols)
+{
+  int rc = enter(ctx);
+  if (rc != 0)
+    return rc;
+  if ((rc = check_volume(vol)) != 0)
+    return rc;
+  static const float eye[9] = { 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f }, zero[3] = { 0.f, 0.f, 0.f }, unit[4] = { 1.f, 1.f, 0.f, 0.f };
+  IntegrateParams p;
+  if ((rc = fill_integrate_params(p, vol, dists_dev, dists_pitch, rows, cols, eye, zero, unit)) != 0)
+    return rc;
+  return launch_integrate_prepare(ctx, p);
 }
 
 int yakhip_integrate_static(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dists_dev, size_t dists_pitch,

@@ -1178,9 +1178,27 @@ static int prepare_checkpoint(yakhip_ctx* ctx, IntegrateParams& p, int slot, int
 // Per-frame set-up shared by the single-frame and the batched launch: the prepass kernel (band
 // thresholds + coarse minima) into slot `slot` of the context's scratch, and the group-test constants.
 // All slots of one launch have the same geometry (same image size, same coarse cap).
+// ahead = true (launch_integrate_prepare): only the prepass, into the slot prepare calls take in turn, noted in
+// ctx->prepared; a later single-frame call for the same image finds it there and launches no prepass of its own.
 static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slots, size_t coarse_cap_bytes,
-                         bool use_static = false)
+                         bool use_static = false, bool ahead = false)
 {
+  bool reuse = false;
+  if (ahead)
+  {
+    slots = 2, slot = ctx->prepared_next;
+    ctx->prepared.valid = false;
+  }
+  else if (ctx->prepared.valid)
+  {
+    // (any other use of the scratch overwrites what was prepared)
+    reuse = !use_static && slots == 1 && ctx->prepared.dists == (const void*)p.dists && ctx->prepared.pitch == p.dists_pitch &&
+            ctx->prepared.rows == p.rows && ctx->prepared.cols == p.cols && ctx->prepared.trunc_hi == p.trunc_hi &&
+            (p.z0 < kCheckpointFrom || !ctx->checkpoint);
+    ctx->prepared.valid = false;
+    if (reuse)
+      slots = 2, slot = ctx->prepared.slot;
+  }
   // ---- per-frame prepass into context-owned scratch: per-pixel band thresholds (8 B/pixel) and
   //      the coarse minima the group test looks up (one float per bk x bk pixel cell) ----
   int bk = 8;
@@ -1205,7 +1223,9 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
   }
   else if (ctx->thr_bytes < slot_bytes * (size_t)slots)
   {
-    if (slot != 0)
+    if (reuse)
+      return fail(YAKHIP_EINVAL, "integrate: the prepared frame's scratch is gone");  // (cannot happen: it was sized then)
+    if (slot != 0 && !ahead)
       return fail(YAKHIP_EINVAL, "integrate: frames of one batch must have the same image size");
     if (ctx->thr)
     {
@@ -1222,10 +1242,16 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
   p.coarse = (const float*)(base + thr_bytes);
   p.cellmin = (const float*)(base + thr_bytes + coarse_bytes);
   p.cellmax = (const float*)(base + thr_bytes + coarse_bytes + cell_bytes);
+  if (ahead)
+    p.ckpt = nullptr;
+  else
   {
     const int rc = prepare_checkpoint(ctx, p, slot, slots, use_static);
     if (rc != 0)
       return rc;
+  }
+  if (!reuse)
+  {
     const uint32_t thr_blocks_x = (uint32_t)((p.cols + 255) / 256);
     const uint32_t thr_blocks = thr_blocks_x * (uint32_t)p.rows;
     const uint32_t cell_blocks = (uint32_t)((p.cw * p.ch + 3) / 4);
@@ -1237,6 +1263,13 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
                        const_cast<float*>(p.ckpt), const_cast<float*>(p.cellmin), const_cast<float*>(p.cellmax), p.ccw,
                        p.cch, cell_blocks);
     YAKHIP_TRY(hipGetLastError());
+  }
+  if (ahead)
+  {
+    ctx->prepared.dists = (const void*)p.dists, ctx->prepared.pitch = p.dists_pitch, ctx->prepared.rows = p.rows;
+    ctx->prepared.cols = p.cols, ctx->prepared.trunc_hi = p.trunc_hi, ctx->prepared.slot = slot, ctx->prepared.valid = true;
+    ctx->prepared_next = slot ^ 1;
+    return 0;
   }
 
   // ---- group-test constants ("Group test") ----
@@ -1459,6 +1492,14 @@ int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in, bool use_stat
     default:
       return launch_variant<1>(ctx, p, chunks, grid, use_static);
   }
+}
+
+int launch_integrate_prepare(yakhip_ctx* ctx, const IntegrateParams& p_in)
+{
+  IntegrateParams p = p_in;
+  if (p.z0 >= kCheckpointFrom && ctx->checkpoint)
+    return 0;  // a deep slab's prepass also computes its column checkpoints from the pose: nothing to do ahead of time
+  return prepare_frame(ctx, p, 0, 1, 32768, false, true);
 }
 
 // ---- multi-camera batched integrate ---------------------------------------------------------------

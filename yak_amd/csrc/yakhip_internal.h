@@ -34,6 +34,18 @@ struct yakhip_ctx
   int mc_z_chunk;      // 0 = default cube layers per marching-cubes tile (tuning)
   void* thr;           // scratch: per-pixel band thresholds of the frame being integrated
   size_t thr_bytes;
+  // yakhip_integrate_prepare: the prepass of a frame already run (on whatever stream was current) into slot
+  // `prepared_slot` of thr; the next yakhip_integrate of the same image takes it from there
+  struct
+  {
+    const void* dists;
+    uint32_t pitch;
+    int rows, cols;
+    float trunc_hi;
+    int slot;
+    bool valid;
+  } prepared;
+  int prepared_next;   // slot the next prepare call writes (0 / 1 in turn)
   void* ckpt;          // scratch: column positions at layer z0 of a deep slab (integrate.hip, checkpoint_kernel)
   size_t ckpt_bytes;
   uint32_t* brick_stats; // device counters {mixed, dead, front, -}, allocated by the "brick_stats" option
@@ -193,6 +205,8 @@ inline size_t surface_cell_words(int X, int Y, int layers)
 // use_static: thresholds / checkpoints go to the file-scope array instead of context-owned buffers, and the
 // call neither allocates nor creates events (yakhip_integrate_static)
 int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p, bool use_static = false);
+// the pose-independent part of launch_integrate's set-up, ahead of time (yakhip_integrate_prepare)
+int launch_integrate_prepare(yakhip_ctx* ctx, const IntegrateParams& p);
 // device address of the CURRENT device's copy of that array (hipGetSymbolAddress; once per context)
 int static_scratch_address(void** out);
 // n_frames >= 1 frames applied in order to the same slab; thr / coarse / grp_* / z_chunk are filled here

@@ -206,6 +206,8 @@ bool KinFu::operator()(const Affine3f& inputCameraMotion, const Affine3f& curren
   cuda::Dists& dists = (frame_counter_ & 1) ? dists_alt_ : dists_;
   beginFrame();  // (goes on with the section if the caller opened it for the upload)
   cuda::computeDists(depth, dists, p.intr);  // :171
+  if (overlap_)
+    volume_->prepareIntegrate(dists);  // (beside the previous frame's work; integrate() below then starts at the walk)
   // :172-186 feed ICP only; the reference runs them on every frame regardless of use_icp, and so
   // does this loop (prev_ must hold frame 0's maps when tracking starts on frame 1)
   cuda::depthBilateralFilter(depth, curr_.depth_pyr[0], p.bilateral_kernel_size, p.bilateral_sigma_spatial,

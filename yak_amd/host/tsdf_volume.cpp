@@ -287,6 +287,13 @@ void TsdfVolume::integrate(const Dists& dists, const Affine3f& camera_motion_tfo
     YAK_CHECK(yakhip_ctx_synchronize(context()));
 }
 
+void TsdfVolume::prepareIntegrate(const Dists& dists)
+{
+  ensureSlab();
+  const yakhip_volume v = view();
+  YAK_CHECK(yakhip_integrate_prepare(context(), &v, dists.ptr(), dists.step(), dists.rows(), dists.cols()));
+}
+
 namespace
 {
 // :114-119 / :133-138: cam2vol = pose_^-1 * camera_pose, Rinv = its rotation inverted (DECOMP_SVD in

@@ -19,7 +19,7 @@ def rodrigues(r):
     return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * K @ K
 
 
-def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None, on_system=None, surface_map=True, overlap=True):
+def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None, on_system=None, surface_map=True, overlap=True, prepare=True):
     """icp: "device" (yakhip_icp_estimate, one wait per frame), "host" (one blocking linearisation at a time,
     numpy solve) or None (true poses supplied).  scene: the frames, if the caller made them already (a list of
     synth.scene_s2(f, noise_mm=1.0) for f in range(frames)).  overlap: the frame's pre-processing goes to the context's
@@ -81,6 +81,8 @@ def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None, on_system=No
             ctx.side_begin()
         e[0].record(torch.cuda.ExternalStream(ctx.stream_handle()) if overlap else None)
         ctx.compute_dists(d.data_ptr(), cols * 2, dists.data_ptr(), cols * 2, rows, cols, intr)
+        if overlap and prepare:
+            ctx.integrate_prepare(desc, dists.data_ptr(), cols * 2, rows, cols)
         ctx.bilateral_filter(d.data_ptr(), cols * 2, cur_d[0].data_ptr(), cols * 2, rows, cols, 7, 4.5, 0.04)
         for l in range(1, LEVELS):
             ctx.depth_pyramid(cur_d[l - 1].data_ptr(), (cols >> (l - 1)) * 2, rows >> (l - 1), cols >> (l - 1),
