@@ -3,6 +3,7 @@
 // reference class (yak/include/yak/kfusion/cuda/tsdf_volume.hpp:10-78; behaviour cited per method
 // in yak_amd/host/tsdf_volume.cpp).
 #pragma once
+#include <vector>
 #include <yak/kfusion/types.hpp>
 
 struct yakhip_volume;
@@ -48,6 +49,12 @@ public:
   virtual void integrate(const Dists& dists, const Affine3f& camera_motion_tform, const Intr& intr);
   virtual void raycast(const Affine3f& camera_pose, const Intr& intr, Depth& depth, Normals& normals);
   virtual void raycast(const Affine3f& camera_pose, const Intr& intr, Cloud& points, Normals& normals);
+
+  /** raycast(points, normals) into level 0 of the two pyramids and their coarser levels (resizePointsNormals level by
+   *  level, kinfu.cpp:294-306) -- on one GPU the first two of them come out of the ray cast's own launch
+   *  (include/yakhip.h, yakhip_raycast_points_pyramid).  Same maps either way.  No counterpart in the reference. */
+  void raycastPyramid(const Affine3f& camera_pose, const Intr& intr, std::vector<Cloud>& points_pyr,
+                      std::vector<Normals>& normals_pyr, int levels);
 
   void swap(CudaData& data);
 

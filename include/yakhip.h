@@ -264,6 +264,17 @@ int yakhip_raycast_depth(yakhip_ctx* ctx, const yakhip_volume* vol, const float 
                          void* depth_dev, size_t depth_pitch, void* normals_dev, size_t normals_pitch, int rows,
                          int cols);
 
+/* yakhip_raycast_points plus the pyramid KinFu builds from its result (kinfu.cpp:294-306: resizePointsNormals level
+ * by level, imgproc.cu:348-395), written by the same launch: the half-size maps (rows / 2 x cols / 2) and, unless
+ * points2_dev and normals2_dev are both null, the quarter-size maps.  Bit for bit the maps of yakhip_raycast_points
+ * followed by yakhip_resize_points_normals per level.  Whole volume only. */
+int yakhip_raycast_points_pyramid(yakhip_ctx* ctx, const yakhip_volume* vol, const float R[9], const float t[3],
+                                  const float Rinv[9], const float intr[4], float step_factor, float gradient_delta_factor,
+                                  void* points_dev, size_t points_pitch, void* normals_dev, size_t normals_pitch, int rows,
+                                  int cols, void* points1_dev, size_t points1_pitch, void* normals1_dev,
+                                  size_t normals1_pitch, void* points2_dev, size_t points2_pitch, void* normals2_dev,
+                                  size_t normals2_pitch);
+
 /* Ray casting over a z-slab of a volume that is spread over several GPUs (option 1).  No
  * counterpart in the reference, which ray-casts one whole volume (tsdf_volume.cu:288-352); the arithmetic
  * is that kernel's.  `vol` describes the layers this GPU HOLDS, [vol->z0, vol->z1): its own layers

@@ -18,7 +18,7 @@ EXPORTS = [
     "yakhip_upload_2d", "yakhip_download_2d", "yakhip_copy", "yakhip_copy_2d",
     "yakhip_clear_volume", "yakhip_surface_map_bytes", "yakhip_surface_map_rebuild", "yakhip_compute_dists", "yakhip_integrate", "yakhip_integrate_static",
     "yakhip_integrate_batch",
-    "yakhip_raycast_points", "yakhip_raycast_depth", "yakhip_raycast_slab", "yakhip_raycast_resolve", "yakhip_raycast_halo",
+    "yakhip_raycast_points", "yakhip_raycast_points_pyramid", "yakhip_raycast_depth", "yakhip_raycast_slab", "yakhip_raycast_resolve", "yakhip_raycast_halo",
     "yakhip_bilateral_filter", "yakhip_truncate_depth", "yakhip_depth_pyramid", "yakhip_compute_points_normals",
     "yakhip_integrate_prepare", "yakhip_resize_points_normals", "yakhip_resize_points_normals2", "yakhip_icp_accumulate", "yakhip_icp_accumulate_rows", "yakhip_icp_estimate",
     "yakhip_marching_cubes", "yakhip_marching_cubes_layers", "yakhip_weld_vertices", "yakhip_extract_cloud", "yakhip_extract_normals",
@@ -124,6 +124,8 @@ def load():
         "yakhip_integrate_batch": [vp, volp, C.POINTER(FrameDesc), i],
         "yakhip_raycast_points": [vp, volp, fp, fp, fp, fp, C.c_float, C.c_float, vp, sz, vp, sz, i, i],
         "yakhip_raycast_depth": [vp, volp, fp, fp, fp, fp, C.c_float, C.c_float, vp, sz, vp, sz, i, i],
+        "yakhip_raycast_points_pyramid": [vp, volp, fp, fp, fp, fp, C.c_float, C.c_float, vp, sz, vp, sz, i, i,
+                                          vp, sz, vp, sz, vp, sz, vp, sz],
         "yakhip_raycast_slab": [vp, volp, i, i, fp, fp, fp, fp, C.c_float, C.c_float, vp, sz, vp, sz, vp, sz, vp, sz, i, i],
         "yakhip_raycast_halo": [volp, C.c_float, C.c_float, C.POINTER(i)],
         "yakhip_raycast_resolve": [vp, volp, i, i, fp, C.c_float, vp, sz, vp, sz, vp, sz, vp, sz, i, i],
@@ -320,6 +322,17 @@ class Context:
         _chk(load().yakhip_raycast_points(self._h, C.byref(vol), _f32(R, 9), _f32(t, 3), _f32(Rinv, 9), _f32(intr, 4),
                                           step_factor, gradient_delta_factor, C.c_void_p(points_ptr), points_pitch,
                                           C.c_void_p(normals_ptr), normals_pitch, rows, cols))
+
+    def raycast_points_pyramid(self, vol, R, t, Rinv, intr, points_ptr, points_pitch, normals_ptr, normals_pitch, rows, cols,
+                               half, quarter=None, step_factor=0.75, gradient_delta_factor=0.5):
+        """raycast_points plus the half- and (optionally) quarter-size maps from the same launch; half / quarter =
+        (points_ptr, points_pitch, normals_ptr, normals_pitch)."""
+        q = quarter if quarter is not None else (None, 0, None, 0)
+        _chk(load().yakhip_raycast_points_pyramid(self._h, C.byref(vol), _f32(R, 9), _f32(t, 3), _f32(Rinv, 9), _f32(intr, 4),
+                                                  step_factor, gradient_delta_factor, C.c_void_p(points_ptr), points_pitch,
+                                                  C.c_void_p(normals_ptr), normals_pitch, rows, cols,
+                                                  C.c_void_p(half[0]), half[1], C.c_void_p(half[2]), half[3],
+                                                  C.c_void_p(q[0]), q[1], C.c_void_p(q[2]), q[3]))
 
     def raycast_depth(self, vol, R, t, Rinv, intr, depth_ptr, depth_pitch, normals_ptr, normals_pitch, rows, cols,
                       step_factor=0.75, gradient_delta_factor=0.5):

@@ -924,13 +924,20 @@ static int raycast_halo_layers(const yakhip_volume* vol, float step_factor, floa
   return h < 1e9 ? (int)h : 1000000000;
 }
 
+// half- and quarter-size outputs of yakhip_raycast_points_pyramid (the quarter size may be absent)
+struct RaycastPyramid
+{
+  void *points[2], *normals[2];
+  size_t points_pitch[2], normals_pitch[2];
+};
+
 // keys == nullptr: the whole volume (vol->z0 = 0, vol->z1 = dims[2]).  Otherwise slab mode: vol holds the
 // layers [z0, z1), of which [z_own0, z_own1) are the slab's own.
 static int raycast_common(yakhip_ctx* ctx, const yakhip_volume* vol, const float R[9], const float t[3],
                           const float Rinv[9], const float intr[4], float step_factor, float gradient_delta_factor,
                           void* points, size_t points_pitch, void* depth, size_t depth_pitch, void* normals,
                           size_t normals_pitch, int rows, int cols, void* keys = nullptr, size_t keys_pitch = 0,
-                          int z_own0 = 0, int z_own1 = 0)
+                          int z_own0 = 0, int z_own1 = 0, const RaycastPyramid* pyr = nullptr)
 {
   int rc = enter(ctx);
   if (rc != 0)
@@ -981,6 +988,27 @@ static int raycast_common(yakhip_ctx* ctx, const yakhip_volume* vol, const float
   p.points = (uint8_t*)points, p.normals = (uint8_t*)normals, p.depth = (uint8_t*)depth;
   p.points_pitch = (uint32_t)points_pitch, p.normals_pitch = (uint32_t)normals_pitch;
   p.depth_pitch = (uint32_t)depth_pitch;
+  for (int l = 0; l < 2; ++l)
+  {
+    p.pyr_points[l] = p.pyr_normals[l] = nullptr;
+    p.pyr_points_pitch[l] = p.pyr_normals_pitch[l] = 0;
+  }
+  if (pyr)
+  {
+    int r = rows, c = cols;
+    for (int l = 0; l < 2 && pyr->points[l]; ++l)
+    {
+      r /= 2, c /= 2;  // imgproc.cu:386-387
+      if (r < 1 || c < 1)
+        return fail(YAKHIP_EINVAL, "raycast_points_pyramid: a %d x %d image has no level %d", cols, rows, l + 1);
+      if ((rc = check_image("raycast_points_pyramid(points)", pyr->points[l], pyr->points_pitch[l], r, c, 16)) != 0)
+        return rc;
+      if ((rc = check_image("raycast_points_pyramid(normals)", pyr->normals[l], pyr->normals_pitch[l], r, c, 16)) != 0)
+        return rc;
+      p.pyr_points[l] = (uint8_t*)pyr->points[l], p.pyr_normals[l] = (uint8_t*)pyr->normals[l];
+      p.pyr_points_pitch[l] = (uint32_t)pyr->points_pitch[l], p.pyr_normals_pitch[l] = (uint32_t)pyr->normals_pitch[l];
+    }
+  }
   p.keys = (uint8_t*)keys, p.keys_pitch = (uint32_t)keys_pitch;
   p.z_base = vol->z0, p.z_held = vol->z1 - vol->z0, p.z_own0 = z_own0, p.z_own1 = z_own1;
   p.skip = (const uint32_t*)vol->surface_map;
@@ -1016,6 +1044,23 @@ int yakhip_raycast_points(yakhip_ctx* ctx, const yakhip_volume* vol, const float
     return fail(YAKHIP_EINVAL, "raycast(points): null image pointer");
   return raycast_common(ctx, vol, R, t, Rinv, intr, step_factor, gradient_delta_factor, points_dev, points_pitch,
                         nullptr, 0, normals_dev, normals_pitch, rows, cols);
+}
+
+int yakhip_raycast_points_pyramid(yakhip_ctx* ctx, const yakhip_volume* vol, const float R[9], const float t[3],
+                                  const float Rinv[9], const float intr[4], float step_factor, float gradient_delta_factor,
+                                  void* points_dev, size_t points_pitch, void* normals_dev, size_t normals_pitch, int rows,
+                                  int cols, void* points1_dev, size_t points1_pitch, void* normals1_dev,
+                                  size_t normals1_pitch, void* points2_dev, size_t points2_pitch, void* normals2_dev,
+                                  size_t normals2_pitch)
+{
+  if (!points_dev || !points1_dev || !normals1_dev)
+    return fail(YAKHIP_EINVAL, "raycast_points_pyramid: null image pointer");
+  if ((points2_dev == nullptr) != (normals2_dev == nullptr))
+    return fail(YAKHIP_EINVAL, "raycast_points_pyramid: the quarter-size maps come as a pair or not at all");
+  RaycastPyramid pyr = { { points1_dev, points2_dev }, { normals1_dev, normals2_dev }, { points1_pitch, points2_pitch },
+                         { normals1_pitch, normals2_pitch } };
+  return raycast_common(ctx, vol, R, t, Rinv, intr, step_factor, gradient_delta_factor, points_dev, points_pitch,
+                        nullptr, 0, normals_dev, normals_pitch, rows, cols, nullptr, 0, 0, 0, &pyr);
 }
 
 int yakhip_raycast_depth(yakhip_ctx* ctx, const yakhip_volume* vol, const float R[9], const float t[3],

@@ -196,6 +196,29 @@ __device__ unsigned long long g_rc_time[kRcSlots][10];
 #define RC_CLOCK(var)
 #define RC_COUNT(var)
 #endif
+// imgproc.cu:348-380 between lanes: the lane holds the top-left value of a 2 x 2 block, the other three are held
+// `right` lanes further on, `down` lanes further on and both.  Same products and sums, in the same order, as
+// resize_pixel (frameproc.hip); lanes whose partners are outside the image or the wave get values nobody stores.
+__device__ __forceinline__ void average_block(int lane, int right, int down, float (&v)[3], float (&n)[3])
+{
+  float v01[3], v10[3], v11[3], n01[3], n10[3], n11[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+  {
+    v01[k] = __shfl(v[k], lane + right, 64), v10[k] = __shfl(v[k], lane + down, 64), v11[k] = __shfl(v[k], lane + down + right, 64);
+    n01[k] = __shfl(n[k], lane + right, 64), n10[k] = __shfl(n[k], lane + down, 64), n11[k] = __shfl(n[k], lane + down + right, 64);
+  }
+  const float prod = v[0] * v01[0] * v10[0] * v11[0];
+  const bool whole = !(prod != prod);
+  const float qnan = __builtin_nanf("");
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+  {
+    v[k] = whole ? (v[k] + v01[k] + v10[k] + v11[k]) * 0.25f : qnan;
+    n[k] = whole ? (n[k] + n01[k] + n10[k] + n11[k]) * 0.25f : qnan;
+  }
+}
+
 template <bool IDX32, bool SLAB, bool SKIP>
 __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, int tiles_x, int n_tiles, int per_xcd)
 {
@@ -516,6 +539,33 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
   {
     float4* prow = (float4*)(p.points + (size_t)y * p.points_pitch);
     prow[x] = make_float4(vx, vy, vz, vw);
+  }
+  if constexpr (!SLAB)
+  {
+    // The pyramid of the maps (kinfu.cpp:294-306 calls resizePointsNormals level by level after the ray cast) from
+    // the registers of the wave: it holds 8 x 8 pixels, lane = 8 * (y & 7) + (x & 7), so every 2 x 2 block of the
+    // full-size maps and every 2 x 2 block of the half-size ones lies in one wave.  (All lanes inside the image
+    // are here together: the march is left lane by lane, but its loop ends before this point.)
+    if (p.pyr_points[0])
+    {
+      float v[3] = { vx, vy, vz }, n[3] = { n0, n1, n2 };
+      average_block(lane, 1, 8, v, n);
+      const int rows1 = p.rows >> 1, cols1 = p.cols >> 1;  // imgproc.cu:386-387
+      if ((lane & 9) == 0 && (y >> 1) < rows1 && (x >> 1) < cols1)
+      {
+        ((float4*)(p.pyr_points[0] + (size_t)(y >> 1) * p.pyr_points_pitch[0]))[x >> 1] = make_float4(v[0], v[1], v[2], 0.f);
+        ((float4*)(p.pyr_normals[0] + (size_t)(y >> 1) * p.pyr_normals_pitch[0]))[x >> 1] = make_float4(n[0], n[1], n[2], 0.f);
+      }
+      if (p.pyr_points[1])
+      {
+        average_block(lane, 2, 16, v, n);
+        if ((lane & 27) == 0 && (y >> 2) < (rows1 >> 1) && (x >> 2) < (cols1 >> 1))
+        {
+          ((float4*)(p.pyr_points[1] + (size_t)(y >> 2) * p.pyr_points_pitch[1]))[x >> 2] = make_float4(v[0], v[1], v[2], 0.f);
+          ((float4*)(p.pyr_normals[1] + (size_t)(y >> 2) * p.pyr_normals_pitch[1]))[x >> 2] = make_float4(n[0], n[1], n[2], 0.f);
+        }
+      }
+    }
   }
   if (p.depth)
   {

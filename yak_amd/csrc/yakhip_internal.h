@@ -175,6 +175,10 @@ struct RaycastParams
   uint8_t* normals;     // float4 image
   uint8_t* depth;       // uint16 image or nullptr
   uint32_t points_pitch, normals_pitch, depth_pitch;
+  // yakhip_raycast_points_pyramid: half- and quarter-size maps (resizePointsNormals of the result, once and twice),
+  // written by the same launch; level[0] null = none, level[1] null = the half size only.  Whole volume only.
+  uint8_t *pyr_points[2], *pyr_normals[2];
+  uint32_t pyr_points_pitch[2], pyr_normals_pitch[2];
   // slab mode (keys != nullptr): vol starts at layer z_base and holds z_held layers, of which the global
   // layers [z_own0, z_own1) are this slab's own; keys = int32 image of march-ending pair indices
   uint8_t* keys;

@@ -271,15 +271,7 @@ bool KinFu::operator()(const Affine3f& inputCameraMotion, const Affine3f& curren
     volume_->integrate(dists, poses_.back(), p.intr);
 
   // :294-306 -- the model as seen from the new pose becomes the next frame's ICP target
-  volume_->raycast(poses_.back(), p.intr, prev_.points_pyr[0], prev_.normals_pyr[0]);
-  {
-    int i = 1;
-    for (; i + 1 < LEVELS; i += 2)  // two levels per launch
-      cuda::resizePointsNormals2(prev_.points_pyr[i - 1], prev_.normals_pyr[i - 1], prev_.points_pyr[i], prev_.normals_pyr[i],
-                                 prev_.points_pyr[i + 1], prev_.normals_pyr[i + 1]);
-    if (i < LEVELS)
-      cuda::resizePointsNormals(prev_.points_pyr[i - 1], prev_.normals_pyr[i - 1], prev_.points_pyr[i], prev_.normals_pyr[i]);
-  }
+  volume_->raycastPyramid(poses_.back(), p.intr, prev_.points_pyr, prev_.normals_pyr, LEVELS);
   if (!overlap_ || cuda::currentShard().world > 1)
     cuda::waitAllDefaultStream();
   if (volume_->raycastOverflowed())  // sharded volume only: more pixels to settle than the composite's list holds

@@ -366,6 +366,41 @@ void TsdfVolume::raycast(const Affine3f& camera_pose, const Intr& intr, Cloud& p
                                   points.ptr(), points.step(), normals.ptr(), normals.step(), points.rows(),
                                   points.cols()));
 }
+void TsdfVolume::raycastPyramid(const Affine3f& camera_pose, const Intr& intr, std::vector<Cloud>& points_pyr,
+                                std::vector<Normals>& normals_pyr, int levels)
+{
+  Cloud& points = points_pyr[0];
+  Normals& normals = normals_pyr[0];
+  int done = 1;
+  if (currentShard().world > 1 || levels < 2 || points.rows() < 4 || points.cols() < 4)
+    raycast(camera_pose, intr, points, normals);
+  else
+  {
+    const RaycastPose rp = raycast_pose(pose_, camera_pose);
+    const float in[4] = { intr.fx, intr.fy, intr.cx, intr.cy };
+    ensureSlab();
+    freshSurfaceMap();
+    const yakhip_volume v = view();
+    done = levels >= 3 ? 3 : 2;
+    for (int i = 1; i < done; ++i)
+    {
+      points_pyr[i].create(points_pyr[i - 1].rows() / 2, points_pyr[i - 1].cols() / 2);
+      normals_pyr[i].create(points_pyr[i - 1].rows() / 2, points_pyr[i - 1].cols() / 2);
+    }
+    YAK_CHECK(yakhip_raycast_points_pyramid(context(), &v, rp.R, rp.t, rp.Rinv, in, raycast_step_factor_, gradient_delta_factor_,
+                                            points.ptr(), points.step(), normals.ptr(), normals.step(), points.rows(),
+                                            points.cols(), points_pyr[1].ptr(), points_pyr[1].step(), normals_pyr[1].ptr(),
+                                            normals_pyr[1].step(), done == 3 ? points_pyr[2].ptr() : nullptr,
+                                            done == 3 ? points_pyr[2].step() : 0, done == 3 ? normals_pyr[2].ptr() : nullptr,
+                                            done == 3 ? normals_pyr[2].step() : 0));
+  }
+  int i = done;
+  for (; i + 1 < levels; i += 2)  // two levels per launch
+    resizePointsNormals2(points_pyr[i - 1], normals_pyr[i - 1], points_pyr[i], normals_pyr[i], points_pyr[i + 1], normals_pyr[i + 1]);
+  if (i < levels)
+    resizePointsNormals(points_pyr[i - 1], normals_pyr[i - 1], points_pyr[i], normals_pyr[i]);
+}
+
 // :147-168.  The volume pose is the affine the points are mapped by; the returned array is a view of the
 // first min(n, capacity) elements of cloud_buffer (DeviceArray(T*, size) does not own).
 DeviceArray<Point> TsdfVolume::fetchCloud(DeviceArray<Point>& cloud_buffer) const

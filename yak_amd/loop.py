@@ -143,12 +143,11 @@ def run_kinfu_loop(ctx, n=512, frames=60, icp="device", scene=None, on_system=No
             cur_p, prv_p = prv_p, cur_p
             cur_n, prv_n = prv_n, cur_n
         else:
-            ctx.raycast_points(desc, np.float32(pose_R).reshape(-1), np.float32(pose_t), np.float32(Rv).reshape(-1), intr,
-                               prv_p[0].data_ptr(), cols * 16, prv_n[0].data_ptr(), cols * 16, rows, cols)
             assert LEVELS == 3
-            ctx.resize_points_normals2(prv_p[0].data_ptr(), cols * 16, prv_n[0].data_ptr(), cols * 16, rows, cols,
-                                       prv_p[1].data_ptr(), (cols >> 1) * 16, prv_n[1].data_ptr(), (cols >> 1) * 16,
-                                       prv_p[2].data_ptr(), (cols >> 2) * 16, prv_n[2].data_ptr(), (cols >> 2) * 16)
+            ctx.raycast_points_pyramid(desc, np.float32(pose_R).reshape(-1), np.float32(pose_t), np.float32(Rv).reshape(-1), intr,
+                                       prv_p[0].data_ptr(), cols * 16, prv_n[0].data_ptr(), cols * 16, rows, cols,
+                                       (prv_p[1].data_ptr(), (cols >> 1) * 16, prv_n[1].data_ptr(), (cols >> 1) * 16),
+                                       (prv_p[2].data_ptr(), (cols >> 2) * 16, prv_n[2].data_ptr(), (cols >> 2) * 16))
         e[4].record()
         tR, tt = c2v(scene[f][1], scene[f][2])
         worst = max(worst, float(np.linalg.norm(pose_t - tt)))
