@@ -201,7 +201,8 @@ int yakhip_integrate(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dist
  * call with the same image (pointer, pitch, size; untouched in between) and truncation distance then launches its
  * walk only; any other integrate call in between discards what was prepared.  Two calls in a row use two scratch
  * areas in turn, so frame f + 1 may be prepared while frame f is still being integrated.  Slabs that start from
- * column checkpoints (z0 >= 64) take nothing from it.  Results are the same bit for bit. */
+ * column checkpoints (z0 >= 64) take nothing from it.  Results are the same bit for bit.  The integrate call must be
+ * ordered behind this one like behind any producer of its image: same stream, or after yakhip_ctx_side_end. */
 int yakhip_integrate_prepare(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dists_dev, size_t dists_pitch, int rows,
                              int cols);
 
