@@ -234,13 +234,40 @@ def kinfu_loop_row(ctx):
              run_kinfu_loop(ctx, VOXELS_PER_RANK_EDGE, frames, "device", scene))
     p = best(run_kinfu_loop(ctx, VOXELS_PER_RANK_EDGE, frames, None, scene),
              run_kinfu_loop(ctx, VOXELS_PER_RANK_EDGE, frames, None, scene))
-    return {"workload": "512^3, the 300 frames of the S2 orbit (1.2 deg per frame, 1 mm depth noise), depth frames resident in HBM; "
-                        "per frame: compute_dists, bilateral, 3-level pyramid, point/normal maps, ICP 10/5/4 linearisations "
-                        "(device-resident loop), integrate, raycast, 2x2 resize; host waits once per frame",
-            "fused_frames_per_s": round(r["frames_per_s"], 1),
-            "fused_frames_per_s_supplied_poses": round(p["frames_per_s"], 1),
-            "worst_position_error_mm": round(r["worst_position_error_mm"], 2),
-            "stage_ms": {k: round(v, 4) for k, v in r["stage_ms"].items()}}
+    out = {"workload": "512^3, the 300 frames of the S2 orbit (1.2 deg per frame, 1 mm depth noise), depth frames resident in HBM; "
+                       "per frame: compute_dists, bilateral, 3-level pyramid, point/normal maps, ICP 10/5/4 linearisations "
+                       "(device-resident loop), integrate, raycast with the maps' 2x2 pyramid; host waits once per frame",
+           "host": "Python over the C ABI (yak_amd/loop.py)",
+           "fused_frames_per_s": round(r["frames_per_s"], 1),
+           "fused_frames_per_s_supplied_poses": round(p["frames_per_s"], 1),
+           "worst_position_error_mm": round(r["worst_position_error_mm"], 2),
+           "stage_ms": {k: round(v, 4) for k, v in r["stage_ms"].items()}}
+    cpp = cpp_loop_rates(frames)
+    if cpp:
+        out["cpp_host"] = cpp
+    return out
+
+
+def cpp_loop_rates(frames):
+    """The same orbit through the C++ classes (kfusion::KinFu in examples/offline_fuse, a child process): its frames
+    come from host memory, so every frame's upload is inside the figure.  None if the example is not built."""
+    import re
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "examples", "offline_fuse")
+    if not os.access(exe, os.X_OK):
+        return None
+    out = {"what": "examples/offline_fuse --n 512 --frames %d [--track]: kfusion::KinFu over the C ABI, per-frame upload included" % frames}
+    for key, extra in (("fused_frames_per_s", ["--track"]), ("fused_frames_per_s_supplied_poses", [])):
+        try:
+            txt = subprocess.run([exe, "--n", "512", "--frames", str(frames)] + extra, capture_output=True, text=True, timeout=120).stdout
+        except (OSError, subprocess.TimeoutExpired):
+            return None
+        m = re.search(r"= (\d+) frames/s", txt)
+        if not m:
+            return None
+        out[key] = int(m.group(1))
+    return out
 
 
 def orbit_views_row(ctx, torch, capi, synth):
