@@ -435,6 +435,33 @@ static void test_kinfu_icp_tracks_orbit()
   // drift bound: half a voxel and half a degree over the run (a lost track is off by the 67 mm / 1.2 deg steps)
   EXPECT(worst_t < 0.5 * 3.0 / 128 && worst_r < 0.5);
 
+  // raycastPyramid (what operator() calls) against the reference's sequence, raycast + resizePointsNormals per
+  // level (kinfu.cpp:294-306), four levels: the same bytes in every map
+  {
+    const Affine3f view = kinfu.getCameraPose();
+    const int levels = 4;
+    std::vector<kfusion::cuda::Cloud> pa(levels), pb(levels);
+    std::vector<kfusion::cuda::Normals> na(levels), nb(levels);
+    pa[0].create(p.rows, p.cols), na[0].create(p.rows, p.cols), pb[0].create(p.rows, p.cols), nb[0].create(p.rows, p.cols);
+    kinfu.tsdf().raycastPyramid(view, p.intr, pa, na, levels);
+    kinfu.tsdf().raycast(view, p.intr, pb[0], nb[0]);
+    for (int i = 1; i < levels; ++i)
+      kfusion::cuda::resizePointsNormals(pb[i - 1], nb[i - 1], pb[i], nb[i]);
+    size_t surface = 0;
+    for (int i = 0; i < levels; ++i)
+    {
+      EXPECT(pa[i].rows() == p.rows >> i && pa[i].cols() == p.cols >> i && na[i].rows() == pb[i].rows() && na[i].cols() == pb[i].cols());
+      const size_t n = (size_t)pa[i].rows() * pa[i].cols() * 4;
+      std::vector<float> a(n), b(n), c(n), d(n);
+      pa[i].download(a.data(), (size_t)pa[i].cols() * 16), pb[i].download(b.data(), (size_t)pb[i].cols() * 16);
+      na[i].download(c.data(), (size_t)na[i].cols() * 16), nb[i].download(d.data(), (size_t)nb[i].cols() * 16);
+      EXPECT(std::memcmp(a.data(), b.data(), n * 4) == 0 && std::memcmp(c.data(), d.data(), n * 4) == 0);
+      for (size_t k = 0; k < n; k += 4)
+        surface += a[k] == a[k];
+    }
+    EXPECT(surface > 10000);
+  }
+
   // a featureless frame makes the normal matrix singular: the loop reports failure and starts over
   // (kinfu.cpp:247-252)
   std::vector<std::uint16_t> blank((size_t)p.rows * p.cols, 0);

@@ -35,7 +35,7 @@ struct yakhip_ctx
   void* thr;           // scratch: per-pixel band thresholds of the frame being integrated
   size_t thr_bytes;
   // yakhip_integrate_prepare: the prepass of a frame already run (on whatever stream was current) into slot
-  // `prepared_slot` of thr; the next yakhip_integrate of the same image takes it from there
+  // prepared.slot of thr (which then holds two); the next yakhip_integrate of the same image takes it from there
   struct
   {
     const void* dists;
