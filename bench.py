@@ -473,7 +473,8 @@ def run_c5(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, e
                        "visited_Gvox_per_s": round(K * C5_LAYERS_PER_RANK * world * n * n * args.steps / elapsed / 1e9, 1),
                        "parallelism": "z-slab x%d" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": load_traffic("integrate_batch_c5_rank%d_of_%d" % (rank, world)),
                          "kernel": "yakhip::integrate_batch_kernel<4, true>", "kernel_ms": round(kernel_ms, 5),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "rank 0's slab; bound by the per-voxel path of the bricks that hold surface, not by HBM "

@@ -42,6 +42,10 @@ how = ("profiles/%s_pmc_fetch.csv + profiles/%s_pmc_write.csv (separate rocprofv
        "FETCH_SIZE (KiB) doubled: on gfx950 the counter reports half the bytes of 64-byte requests (MI355X_MICROARCH.md, HBM section; "
        "calibrated with tools/fetch_calib.hip: a 512 MiB buffer read once reports 262147 KiB)" % (tag, tag))
 out = collections.OrderedDict()
+try:  # entries other scripts added (tools/collect_c5_traffic.py) stay
+    out.update(json.load(open(os.path.join(dst, "traffic.json")), object_pairs_hook=collections.OrderedDict))
+except (OSError, ValueError):
+    pass
 f, n = mean_kib(fetch, "FETCH_SIZE", "integrate_kernel<4, true>")
 w, _ = mean_kib(write, "WRITE_SIZE", "integrate_kernel<4, true>")
 out["integrate_s0_n1"] = {"kernel": "yakhip::integrate_kernel<4, true>", "launches": n, "FETCH_SIZE_KiB": round(f), "WRITE_SIZE_KiB": round(w),
