@@ -73,6 +73,16 @@ def main():
     print("  4 cameras, one sweep (integrate_batch): %.3f ms = %.3f ms per frame, %.0f Gvox/s visited; 4 single-frame calls: "
           "%.3f ms; %d voxels touched (%.1f %%)" % (ms_batch, ms_batch / 4, 4 * voxels / ms_batch / 1e6, ms_seq, touched,
                                                     100.0 * touched / voxels))
+    # what the wave bricks of each camera are (the single-frame kernel counts them; the sweep classifies the same bricks)
+    ctx.set_option("brick_stats", 1)
+    ctx.brick_stats()
+    for k, fr in enumerate(frames):
+        ctx.integrate(held, *fr)  # (not timed: the counting costs an atomic per wave)
+        torch.cuda.synchronize()
+        st = ctx.brick_stats()
+        tot = max(sum(st.values()), 1)
+        print("  camera %d alone: wave bricks %s" % (k, ", ".join("%s %.1f %%" % (c, 100.0 * v / tot) for c, v in sorted(st.items()))))
+    ctx.set_option("brick_stats", 0)
     ntri = ctx.marching_cubes(held, 2, vs[0])
     tri = torch.empty((max(ntri, 1), 9), dtype=torch.float32, device="cuda")
     ms_mc = timed(lambda: ctx.marching_cubes(held, 2, vs[0], tri.data_ptr(), ntri), args.reps)
