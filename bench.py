@@ -267,6 +267,9 @@ def cpp_loop_rates(frames):
         if not m:
             return None
         out[key] = int(m.group(1))
+        m = re.search(r"\((\d+) frames/s after the first (\d+)\)", txt)
+        if m:  # without the frames that carry allocations and first launches
+            out[key + "_after_the_first_%s" % m.group(2)] = int(m.group(1))
     return out
 
 
