@@ -198,7 +198,8 @@ int yakhip_integrate(yakhip_ctx* ctx, const yakhip_volume* vol, const void* dist
 /* Optional, no counterpart in the reference: the part of yakhip_integrate's work that does not depend on the pose
  * (per-pixel band thresholds and the coarse planes its culling tests read), ahead of time and on whatever stream is
  * current -- e.g. between yakhip_ctx_side_begin / _end, beside the previous frame's work.  The next yakhip_integrate
- * call with the same image (pointer, pitch, size; untouched in between) and truncation distance then launches its
+ * call with the same image (pointer, pitch, size; not written in between -- a yakhip_compute_dists, upload or copy into
+ * it through this context discards what was prepared, other writers must not touch it) and truncation distance then launches its
  * walk only; any other integrate call in between discards what was prepared.  Two calls in a row use two scratch
  * areas in turn, so frame f + 1 may be prepared while frame f is still being integrated.  Slabs that start from
  * column checkpoints (z0 >= 64) take nothing from it.  Results are the same bit for bit.  The integrate call must be

@@ -113,3 +113,37 @@ def test_prepare_after_a_smaller_frame_grows_the_scratch(gpu_ctx):
     gpu_ctx.integrate_prepare(desc, la.data_ptr(), 640, 240, 320)  # larger image: the scratch is replaced
     gpu_ctx.integrate(desc, la.data_ptr(), 640, 240, 320, R.reshape(-1), t, intr_l)
     assert np.array_equal(_words(vol), want)
+
+
+def test_an_image_rewritten_through_the_library_is_not_taken_from_what_was_prepared(gpu_ctx):
+    dims, z0, z1, rows, cols = (64, 48, 40), 0, 40, 120, 160
+    vs, tr, intr, R, t, da, db = _setup(dims, z0, z1, rows, cols)
+    args = (da.data_ptr(), cols * 2, rows, cols, R.reshape(-1), t, intr)
+    depth = torch.from_numpy(np.full((rows, cols), 2300, dtype=np.int16)).cuda()
+    img_b = db.cpu().numpy().copy()
+
+    def rewrite(how):
+        if how == "compute_dists":
+            gpu_ctx.compute_dists(depth.data_ptr(), cols * 2, da.data_ptr(), cols * 2, rows, cols, intr)
+        elif how == "upload":
+            gpu_ctx.upload(da.data_ptr(), img_b.ctypes.data, img_b.nbytes)
+        else:
+            gpu_ctx.copy(da.data_ptr(), db.data_ptr(), img_b.nbytes)
+
+    for how in ("compute_dists", "upload", "copy"):
+        original = da.clone()
+        vol, desc = _volume(dims, vs, tr, z0, z1)
+        rewrite(how)
+        gpu_ctx.integrate(desc, *args)
+        want = _words(vol)
+        da.copy_(original)
+        torch.cuda.synchronize()
+        vol, desc = _volume(dims, vs, tr, z0, z1)
+        gpu_ctx.integrate_prepare(desc, da.data_ptr(), cols * 2, rows, cols)  # thresholds of the ORIGINAL image
+        rewrite(how)
+        gpu_ctx.integrate(desc, *args)
+        got = _words(vol)
+        da.copy_(original)
+        torch.cuda.synchronize()
+        assert np.count_nonzero(want >> 16) > 0
+        assert np.array_equal(got, want), "%s: %d voxel words differ" % (how, np.count_nonzero(got != want))

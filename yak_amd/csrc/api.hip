@@ -567,12 +567,24 @@ static int stage_buffers(yakhip_ctx* ctx)
 }
 
 // rows x width bytes between pitched host memory and pitched device memory, blocking
+// yakhip_integrate_prepare remembers an image by its address: a library call that writes [dst, dst + bytes) makes
+// what was prepared from that image stale
+static void forget_prepared(yakhip_ctx* ctx, const void* dst, size_t bytes)
+{
+  const uint8_t* img = (const uint8_t*)ctx->prepared.dists;
+  if (ctx->prepared.valid && img + (size_t)ctx->prepared.pitch * (size_t)ctx->prepared.rows > (const uint8_t*)dst &&
+      img < (const uint8_t*)dst + bytes)
+    ctx->prepared.valid = false;
+}
+
 static int staged_copy(yakhip_ctx* ctx, uint8_t* dev, size_t dev_pitch, uint8_t* host, size_t host_pitch, size_t width,
                        size_t rows, bool to_device)
 {
   int rc = stage_buffers(ctx);
   if (rc != 0)
     return rc;
+  if (to_device)
+    forget_prepared(ctx, dev, dev_pitch * (rows - 1) + width);
   if (dev_pitch == width && host_pitch == width)
   {  // contiguous on both sides: one long row, cut into pieces below
     width *= rows;
@@ -670,6 +682,7 @@ int yakhip_copy(yakhip_ctx* ctx, void* dst_dev, const void* src_dev, size_t byte
     return fail(YAKHIP_EINVAL, "copy: null pointer");
   if (bytes == 0)
     return 0;
+  forget_prepared(ctx, dst_dev, bytes);
   YAKHIP_TRY(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
 }
@@ -686,6 +699,7 @@ int yakhip_copy_2d(yakhip_ctx* ctx, void* dst_dev, size_t dst_pitch, const void*
     return fail(YAKHIP_EINVAL, "copy_2d: pitch smaller than a row");
   if (width_bytes == 0 || rows == 0)
     return 0;
+  forget_prepared(ctx, dst_dev, dst_pitch * (rows - 1) + width_bytes);
   YAKHIP_TRY(hipMemcpy2DAsync(dst_dev, dst_pitch, src_dev, src_pitch, width_bytes, rows, hipMemcpyDeviceToDevice,
                               ctx->stream));
   return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
@@ -791,6 +805,7 @@ int yakhip_compute_dists(yakhip_ctx* ctx, const void* depth_dev, size_t depth_pi
     return rc;
   if (rows > 65535)
     return fail(YAKHIP_ERANGE, "compute_dists: more than 65535 rows");
+  forget_prepared(ctx, dists_dev, dists_pitch * (size_t)(rows - 1) + (size_t)cols * 2u);
   return launch_compute_dists(ctx, (const uint8_t*)depth_dev, depth_pitch, (uint8_t*)dists_dev, dists_pitch, rows,
                               cols, intr[0], intr[1], intr[2], intr[3]);
 }
