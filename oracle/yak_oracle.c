@@ -12,6 +12,8 @@
  *   __fmaf_rn -> fmaf          __fsqrt_rn / sqrtf -> sqrtf (correctly rounded)
  *   __fdividef -> IEEE '/'     __float2half[_rn] -> yko_float2half_rn (RNE)
  *   tex2D point fetch, unnormalised coords -> texel (floor(x), floor(y))
+ *   __float2int_rd of a NaN pixel coordinate (gives 0 on the device; only a non-finite pose or intrinsics
+ *   produce one) -> the voxel is skipped, see integrate_column
  *
  * Citations are relative to /root/reference/yak/.
  */
@@ -202,8 +204,10 @@ static void integrate_column(uint32_t* slab, int x, int y, const int dims[3], in
     const float coox = fmaf(fx, vcx / vcz, cx);
     const float cooy = fmaf(fy, vcy / vcz, cy);
 
-    /* :83 */
-    if (coox < 0.f || cooy < 0.f || coox >= (float)cols || cooy >= (float)rows)
+    /* :83 -- the reference tests the converted integers; floor(coo) lies inside the image <=> 0 <= coo < size.
+     * Written so that a NaN coordinate (non-finite pose or intrinsics) is rejected: __float2int_rd turns a NaN into
+     * 0 and the reference then reads row / column 0 of the image -- not reproduced, here or in the HIP kernel. */
+    if (!(coox >= 0.f && cooy >= 0.f && coox < (float)cols && cooy < (float)rows))
       continue;
 
     /* :87  point-filtered, unnormalised texture fetch of a half texel */

@@ -517,3 +517,62 @@ def test_integrate_brick_test_classes_on_known_scenes(gpu_ctx):
     assert s0["front"] > 0 and s0["dead"] == 0 and s0["mixed"] == 0, s0
     assert not none.any()
     assert s1["dead"] > 0 and s1["front"] == 0 and s1["mixed"] == 0, s1
+
+
+DEGENERATE = {
+    "scaled rotation": lambda R, t, i: (1.5 * R, t, i),
+    "mirrored": lambda R, t, i: (R * np.array([[-1.0], [1.0], [1.0]], dtype=np.float32), t * np.array([-1, 1, 1], dtype=np.float32), i),
+    "negative fx": lambda R, t, i: (R, t, (-i[0], i[1], i[2], i[3])),
+    "negative fy": lambda R, t, i: (R, t, (i[0], -i[1], i[2], i[3])),
+    "NaN translation": lambda R, t, i: (R, np.array([t[0], np.nan, t[2]], dtype=np.float32), i),
+    "NaN rotation entry": lambda R, t, i: (np.where(np.eye(3) > 0, R, np.float32(np.nan)).astype(np.float32), t, i),
+    "infinite translation": lambda R, t, i: (R, np.array([t[0], t[1], np.inf], dtype=np.float32), i),
+    "camera a thousand kilometres away": lambda R, t, i: (R, t + np.float32(1e6), i),
+    "zero rotation": lambda R, t, i: (np.zeros((3, 3), dtype=np.float32), np.array([0.1, -0.05, 1.7], dtype=np.float32), i),
+    "huge focal length": lambda R, t, i: (R, t, (1e7, 1e7, i[2], i[3])),
+    "tiny focal length": lambda R, t, i: (R, t, (1e-3, 1e-3, i[2], i[3])),
+    "principal point far outside": lambda R, t, i: (R, t, (i[0], i[1], -5000.0, 9000.0)),
+    "NaN principal point": lambda R, t, i: (R, t, (i[0], i[1], float("nan"), i[3])),
+}
+
+
+@pytest.mark.parametrize("case", sorted(DEGENERATE))
+def test_integrate_degenerate_poses_and_intrinsics(gpu_ctx, case):
+    """Poses and intrinsics no camera has: the culling tests switch themselves off where their assumptions fail
+    (finite pose, positive focal lengths) and the per-voxel path must still do what tsdf_volume.cu:51-110 does with
+    such numbers -- the oracle's word for it, voxel word for voxel word, on top of an ordinary frame."""
+    depth, R, t = synth.scene_s2(40)
+    dists = oracle.compute_dists(depth, synth.INTR)
+    dims, vs, tr = synth.volume_geometry((48, 40, 56))
+    want = np.zeros(48 * 40 * 56, dtype=np.uint32)
+    oracle.integrate(want, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR, nthreads=oracle.max_threads())
+    got = gpu_integrate(gpu_ctx, np.zeros_like(want), dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR)
+    assert_parity(got, want)
+    R2, t2, intr2 = DEGENERATE[case](np.asarray(R, dtype=np.float32).reshape(3, 3), np.asarray(t, dtype=np.float32), synth.INTR)
+    oracle.integrate(want, dims, vs, tr, synth.MAX_WEIGHT, dists, R2, t2, intr2, nthreads=oracle.max_threads())
+    got = gpu_integrate(gpu_ctx, got, dims, vs, tr, synth.MAX_WEIGHT, dists, R2, t2, intr2)
+    assert_parity(got, want)
+
+
+@pytest.mark.parametrize("rows,cols", [(1080, 1920), (1, 1), (2, 3), (9, 700), (1200, 17)])
+def test_integrate_image_sizes_from_one_pixel_to_full_hd(gpu_ctx, rows, cols):
+    """Images far from 640 x 480: the prepass picks coarser cells for a large image and the culling planes of a tiny
+    one hold a single cell."""
+    rng = np.random.default_rng(rows * 7 + cols)
+    intr = (0.8 * max(cols, 8), 0.8 * max(cols, 8), cols / 2 - 0.5, rows / 2 - 0.5)
+    v, u = np.mgrid[0:rows, 0:cols].astype(np.float32)
+    depth = 2100.0 + 300.0 * np.sin(u / max(cols, 2) * 6.0) + 200.0 * np.cos(v / max(rows, 2) * 5.0) + rng.normal(0, 2, (rows, cols))
+    depth[rng.random((rows, cols)) < 0.03] = 0
+    depth = np.clip(depth, 0, 65535).astype(np.uint16)
+    dists = oracle.compute_dists(depth, intr)
+    dims, vs, tr = synth.volume_geometry((56, 44, 48))
+    ex, ey = dims[0] * vs[0], dims[1] * vs[1]
+    R = np.eye(3, dtype=np.float32)
+    t = np.array([-ex / 2, -ey / 2, 0.8], dtype=np.float32)
+    want = np.zeros(56 * 44 * 48, dtype=np.uint32)
+    got = np.zeros_like(want)
+    for _ in range(2):
+        _, updated = oracle.integrate(want, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, intr, nthreads=oracle.max_threads())
+        got = gpu_integrate(gpu_ctx, got, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, intr)
+        assert_parity(got, want)
+    assert updated > 0

@@ -228,3 +228,55 @@ def test_raycast_rejects_bad_arguments(gpu_ctx):
         gpu_ctx.raycast_points(whole, eye, t, eye, synth.INTR, img.data_ptr(), 128, img.data_ptr(), 128, 8, 8,
                                step_factor=0.0)
     assert e.value.code == -1
+
+
+def _looking_along_z(eye):
+    """cam2vol of a camera at `eye` whose axes are the volume's: pixel (cy, cx) looks exactly along +z."""
+    return np.eye(3, dtype=np.float32), np.asarray(eye, dtype=np.float32)
+
+
+RAY_CASES = {
+    # rays with a zero direction component (1 / 0 = inf in the slab test, cu:149-165) ...
+    "axis-aligned central ray": lambda R, t: _looking_along_z((1.47, 1.53, -1.0)),
+    # ... and the camera exactly on a face plane of the box besides: inf * 0 = NaN in the slab test
+    "axis-aligned ray in the x = 0 plane": lambda R, t: _looking_along_z((0.0, 1.5, -1.0)),
+    "camera on the z = 0 face": lambda R, t: _looking_along_z((1.5, 1.5, 0.0)),
+    "camera on the far corner of the box": lambda R, t: (R, np.array([3.0, 3.0, 3.0], dtype=np.float32) * np.float32(63.0 / 64.0)),
+    "scaled rotation": lambda R, t: (np.float32(2.5) * R, t),
+    "mirrored": lambda R, t: (R * np.array([[1.0, -1.0, 1.0]], dtype=np.float32), t),
+    "zero rotation": lambda R, t: (np.zeros((3, 3), dtype=np.float32), t),
+    "NaN translation": lambda R, t: (R, np.array([t[0], np.nan, t[2]], dtype=np.float32)),
+    "NaN rotation entry": lambda R, t: (np.where(np.eye(3) > 0, R, np.float32(np.nan)).astype(np.float32), t),
+    "infinite translation": lambda R, t: (R, np.array([np.inf, t[1], t[2]], dtype=np.float32)),
+    "camera a thousand kilometres away": lambda R, t: (R, (t - np.float32(1e6) * R[:, 2]).astype(np.float32)),
+}
+
+
+@pytest.mark.parametrize("with_map", [False, True])
+@pytest.mark.parametrize("case", sorted(RAY_CASES))
+def test_raycast_degenerate_rays_and_poses(gpu_ctx, case, with_map):
+    """Rays the slab test divides by zero for, cameras on the box, poses no camera has: the maps must be the oracle's
+    (tsdf_volume.cu:149-165, 288-352 with IEEE inf / NaN arithmetic), with the surface map and without."""
+    vol_h, dims, vs, tr = fused_volume(64, [0, 60, 150, 240], scene="s2")
+    _, R_v2c, t_v2c = synth.scene_s2(20)
+    R0, t0 = cam2vol(R_v2c, t_v2c)
+    R, t = RAY_CASES[case](np.asarray(R0, dtype=np.float32).reshape(3, 3), np.asarray(t0, dtype=np.float32))
+    Rinv = np.ascontiguousarray(np.asarray(R_v2c, dtype=np.float32))
+    rows, cols, intr = 120, 160, (131.0, 131.0, 80.0, 60.0)  # integer principal point: pixel (60, 80) has rx = ry = 0
+    want_p, want_n, _, hits = oracle.raycast(vol_h, dims, vs, tr, R, t, Rinv, intr, rows, cols, nthreads=8)
+    vol = torch.from_numpy(vol_h.view(np.int32)).cuda()
+    if with_map:
+        plain = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT)
+        smap = torch.zeros(capi.surface_map_bytes(plain) // 4, dtype=torch.int32, device="cuda")
+        desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT, surface_map=smap.data_ptr())
+        gpu_ctx.surface_map_rebuild(desc)
+    else:
+        desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT)
+    pts = torch.full((rows, cols, 4), 7.0, dtype=torch.float32, device="cuda")
+    nrm = torch.full((rows, cols, 4), 7.0, dtype=torch.float32, device="cuda")
+    gpu_ctx.raycast_points(desc, R.reshape(-1), t, Rinv.reshape(-1), intr, pts.data_ptr(), cols * 16, nrm.data_ptr(), cols * 16,
+                           rows, cols)
+    torch.cuda.synchronize()
+    assert_parity(pts.cpu().numpy(), nrm.cpu().numpy(), want_p, want_n)
+    if case in ("axis-aligned central ray", "scaled rotation", "mirrored", "camera on the z = 0 face"):
+        assert hits > 100, "%s: the case is meant to see the surface (%d hits)" % (case, hits)
