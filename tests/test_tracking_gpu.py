@@ -449,3 +449,62 @@ def test_fusion_loop_with_the_side_stream_gives_the_same_volume_and_poses(gpu_ct
     gpu_ctx.side_end()
     with pytest.raises(capi.YakHipError):
         gpu_ctx.side_end()
+
+
+@pytest.mark.parametrize("rows,cols", [(2, 2), (3, 5), (2, 67), (33, 2), (480, 640)])
+@pytest.mark.parametrize("content", ["zeros", "max", "full range"])
+def test_preprocessing_extreme_depths_and_tiny_images(gpu_ctx, rows, cols, content):
+    """No return anywhere, the largest depth everywhere, every 16-bit value: truncation and pyramid exact, the
+    bilateral filter within its stated bar, point / normal maps the same bits, down to a 2 x 2 image."""
+    rng = np.random.default_rng(rows * 1000 + cols)
+    depth = {"zeros": np.zeros((rows, cols), dtype=np.uint16), "max": np.full((rows, cols), 65535, dtype=np.uint16),
+             "full range": rng.integers(0, 65536, size=(rows, cols), dtype=np.uint16)}[content]
+    src = dev_u16(depth, 3)
+    dst = torch.full_like(src, 9)
+    gpu_ctx.bilateral_filter(src.data_ptr(), src.stride(0) * 2, dst.data_ptr(), dst.stride(0) * 2, rows, cols, 7, 4.5, 0.04)
+    torch.cuda.synchronize()
+    out = dst.cpu().numpy()
+    assert (out[:, cols:] == 9).all()
+    got = np.ascontiguousarray(out[:, :cols]).view(np.uint16)
+    want = oracle.bilateral_filter(depth, 7, 4.5, 0.04)
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1 and (diff != 0).mean() <= max(BILATERAL_MISMATCH_RATE, 1.0 / (rows * cols) if rows * cols < 1000 else 0)
+
+    d = dev_u16(depth)
+    gpu_ctx.truncate_depth(d.data_ptr(), d.stride(0) * 2, rows, cols, 30.0)
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy().view(np.uint16), oracle.truncate_depth(depth, 30.0))
+
+    half = torch.full((rows // 2, cols // 2), 9, dtype=torch.int16, device="cuda")
+    s = dev_u16(depth)
+    gpu_ctx.depth_pyramid(s.data_ptr(), s.stride(0) * 2, rows, cols, half.data_ptr(), half.stride(0) * 2, 0.04)
+    torch.cuda.synchronize()
+    assert np.array_equal(half.cpu().numpy().view(np.uint16), oracle.depth_pyramid(depth, 0.04))
+
+    intr = (0.9 * max(cols, 4), 0.9 * max(cols, 4), cols / 2 - 0.5, rows / 2 - 0.5)
+    pts, nrm = gpu_points_normals(gpu_ctx, depth, intr, pad=2)
+    want_p, want_n = oracle.compute_points_normals(depth, intr)
+    ph, nh = pts.cpu().numpy(), nrm.cpu().numpy()
+    assert (ph[:, cols:] == 9).all() and (nh[:, cols:] == 9).all()
+    assert same_maps(ph[:, :cols], want_p) and same_maps(nh[:, :cols], want_n)
+
+
+ICP_POSES = {
+    "NaN translation": (np.eye(3), [0.0, np.nan, 0.0]),
+    "NaN rotation entry": (np.where(np.eye(3) > 0, 1.0, np.nan), [0.0, 0.0, 0.0]),
+    "infinite translation": (np.eye(3), [0.0, 0.0, np.inf]),
+    "scaled rotation": (1.3 * np.eye(3), [0.01, 0.0, 0.02]),
+    "mirrored": (np.diag([-1.0, 1.0, 1.0]), [0.0, 0.0, 0.0]),
+    "zero rotation": (np.zeros((3, 3)), [0.0, 0.0, 1.5]),
+    "far away": (np.eye(3), [0.0, 0.0, 1e6]),
+}
+
+
+@pytest.mark.parametrize("case", sorted(ICP_POSES))
+def test_icp_accumulate_degenerate_poses(gpu_ctx, case):
+    """Poses no track produces: every pixel must land in the oracle's outcome class (find_coresp, proj_icp.cu:74-102,
+    with IEEE inf / NaN arithmetic) and the sums must agree to the usual bar."""
+    vprev, nprev, _, _ = level_maps(20, 1)
+    vcurr, ncurr, _, _ = level_maps(22, 1)
+    R, t = ICP_POSES[case]
+    check_icp(gpu_ctx, np.asarray(R, dtype=np.float64), np.asarray(t, dtype=np.float64), 1, vcurr, ncurr, vprev, nprev)
