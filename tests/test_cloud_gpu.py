@@ -123,3 +123,15 @@ def test_cloud_512_volume_fused_on_gpu(gpu_ctx):
     want = oracle.extract_cloud(vol.cpu().numpy().view(np.uint32), dims, vs, POSE_R, POSE_T)
     assert len(got) == len(want) > 300000
     assert np.array_equal(canon(got), canon(want))
+
+
+@pytest.mark.parametrize("dims", [(70, 19, 21), (64, 8, 40)])
+def test_cloud_of_a_volume_of_arbitrary_finite_words(gpu_ctx, dims):
+    from test_mc_gpu import arbitrary_words
+
+    vol = arbitrary_words(dims, sum(dims) + 3)
+    vs = (0.01, 0.013, 0.009)
+    want = oracle.extract_cloud(vol, dims, vs, POSE_R, POSE_T)
+    got, _ = gpu_cloud(gpu_ctx, torch.from_numpy(vol.view(np.int32)).cuda(), dims, vs)
+    assert len(got) == len(want) > 30
+    assert np.array_equal(canon(got), canon(want))

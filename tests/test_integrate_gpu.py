@@ -576,3 +576,33 @@ def test_integrate_image_sizes_from_one_pixel_to_full_hd(gpu_ctx, rows, cols):
         got = gpu_integrate(gpu_ctx, got, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, intr)
         assert_parity(got, want)
     assert updated > 0
+
+
+@pytest.mark.parametrize("kind", ["finite halves, any weight", "any 32-bit word"])
+def test_integrate_over_a_volume_of_arbitrary_words(gpu_ctx, kind):
+    """A volume that did not come from integrate (uploadTSDF takes any words): weights above max_weight and, in the
+    second case, infinite and NaN halves.  The running average follows the oracle's arithmetic word for word where the
+    stored tsdf is finite; a NaN stays a NaN (its payload bits are the conversion's business and not compared)."""
+    rng = np.random.default_rng(11)
+    dims, vs, tr = synth.volume_geometry((48, 40, 56))
+    n = 48 * 40 * 56
+    words = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+    if kind == "finite halves, any weight":
+        h = (words & 0xFFFF).astype(np.uint16)
+        h = np.where((h & 0x7C00) == 0x7C00, h & 0xBBFF, h)  # clear an exponent bit of inf / NaN codes
+        words = (words & 0xFFFF0000) | h
+    depth, R, t = synth.scene_s2(40)
+    dists = oracle.compute_dists(depth, synth.INTR)
+    want = words.copy()
+    got = words.copy()
+    for _ in range(2):
+        oracle.integrate(want, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR, nthreads=oracle.max_threads())
+        got = gpu_integrate(gpu_ctx, got, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR)
+    assert np.count_nonzero(want != words) > 1000
+    assert np.array_equal(got >> 16, want >> 16), "weights differ"
+    hw, hg = (want & 0xFFFF).astype(np.uint16), (got & 0xFFFF).astype(np.uint16)
+    nan_w, nan_g = (hw & 0x7FFF) > 0x7C00, (hg & 0x7FFF) > 0x7C00
+    assert np.array_equal(nan_w, nan_g), "NaN voxels differ"
+    assert np.array_equal(hg[~nan_w], hw[~nan_w]), "%d finite tsdf values differ" % np.count_nonzero(hg[~nan_w] != hw[~nan_w])
+    if kind == "finite halves, any weight":
+        assert not nan_w.any() and np.array_equal(got, want)

@@ -237,3 +237,24 @@ def test_weld_signed_zeros_duplicates_and_edges(gpu_ctx):
     with pytest.raises(capi.YakHipError) as e:
         gpu_ctx.weld_vertices(0, 5, 0, 0)
     assert e.value.code == -1
+
+
+def arbitrary_words(dims, seed, finite=True):
+    """Any 32-bit voxel words (what uploadTSDF may bring): every half -- huge, denormal, signed zero -- and every
+    weight, the 'negative' ones included; with finite=True the infinite and NaN codes lose an exponent bit."""
+    rng = np.random.default_rng(seed)
+    words = rng.integers(0, 2 ** 32, size=int(np.prod(dims)), dtype=np.uint64).astype(np.uint32)
+    if finite:
+        h = (words & 0xFFFF).astype(np.uint16)
+        h = np.where((h & 0x7C00) == 0x7C00, h & 0xBBFF, h)
+        words = (words & 0xFFFF0000) | h
+    return words
+
+
+@pytest.mark.parametrize("dims,min_weight", [((70, 19, 21), 0), ((64, 8, 40), 5), ((33, 30, 18), 20000)])
+def test_mc_volume_of_arbitrary_finite_words(gpu_ctx, dims, min_weight):
+    vol = arbitrary_words(dims, sum(dims) + 7)
+    want = oracle.marching_cubes(vol, dims, min_weight, 0.37)
+    got = gpu_mc(gpu_ctx, torch.from_numpy(vol.view(np.int32)).cuda(), dims, min_weight, 0.37)
+    assert len(got) == len(want) > 50
+    assert np.array_equal(canon(got), canon(want))

@@ -280,3 +280,35 @@ def test_raycast_degenerate_rays_and_poses(gpu_ctx, case, with_map):
     assert_parity(pts.cpu().numpy(), nrm.cpu().numpy(), want_p, want_n)
     if case in ("axis-aligned central ray", "scaled rotation", "mirrored", "camera on the z = 0 face"):
         assert hits > 100, "%s: the case is meant to see the surface (%d hits)" % (case, hits)
+
+
+@pytest.mark.parametrize("with_map", [False, True])
+@pytest.mark.parametrize("finite", [True, False])
+def test_raycast_through_a_volume_of_arbitrary_words(gpu_ctx, finite, with_map):
+    """Any voxel words (uploadTSDF): every sample pair is a candidate crossing, interpolation runs on huge and
+    denormal halves and, with finite=False, on infinities and NaNs.  Same maps as the oracle, lane for lane: NaN where
+    it has NaN, the same bits elsewhere."""
+    from test_mc_gpu import arbitrary_words
+
+    dims, vs, tr = synth.volume_geometry((48, 40, 56))
+    vol_h = arbitrary_words(dims, 99, finite)
+    _, R_v2c, t_v2c = synth.scene_s2(20)
+    R, t = cam2vol(R_v2c, t_v2c)
+    rows, cols, intr = 120, 160, (131.0, 131.0, 79.5, 59.5)
+    want_p, want_n, _, hits = oracle.raycast(vol_h, dims, vs, tr, R, t, R_v2c, intr, rows, cols, nthreads=8)
+    assert hits > 1000
+    vol = torch.from_numpy(vol_h.view(np.int32)).cuda()
+    desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT)
+    if with_map:
+        smap = torch.zeros(capi.surface_map_bytes(desc) // 4, dtype=torch.int32, device="cuda")
+        desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT, surface_map=smap.data_ptr())
+        gpu_ctx.surface_map_rebuild(desc)
+    pts = torch.full((rows, cols, 4), 7.0, dtype=torch.float32, device="cuda")
+    nrm = torch.full((rows, cols, 4), 7.0, dtype=torch.float32, device="cuda")
+    gpu_ctx.raycast_points(desc, np.asarray(R).reshape(-1), t, np.asarray(R_v2c).reshape(-1), intr, pts.data_ptr(), cols * 16,
+                           nrm.data_ptr(), cols * 16, rows, cols)
+    torch.cuda.synchronize()
+    for got, want in ((pts.cpu().numpy(), want_p), (nrm.cpu().numpy(), want_n)):
+        nan = np.isnan(want)
+        assert np.array_equal(np.isnan(got), nan)
+        assert np.array_equal(got[~nan].view(np.uint32), want[~nan].view(np.uint32))
