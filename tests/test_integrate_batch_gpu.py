@@ -160,3 +160,44 @@ def test_batch_rejects_bad_arguments(gpu_ctx):
     with pytest.raises(capi.YakHipError) as e:   # null image
         gpu_ctx.integrate_batch(desc, [(0, 1280, 480, 640, eye, t, synth.INTR)])
     assert e.value.code == -1
+
+
+@pytest.mark.parametrize("bad_at", [0, 2, 3])
+def test_batch_with_a_frame_whose_pose_no_camera_has(gpu_ctx, bad_at):
+    """One frame of the four has a non-finite, a mirrored or a negative-focal-length pose: the culling tests are per
+    workgroup, so they are off for the whole sweep; every frame must still be folded as the oracle folds it, in order,
+    over a volume of arbitrary finite words."""
+    rng = np.random.default_rng(5 + bad_at)
+    dims, vs, tr = synth.volume_geometry((64, 48, 40))
+    frames = frames_s2([0, 75, 150, 225], noise=1.0)
+    dists, R, t, intr = frames[bad_at]
+    R = np.asarray(R, dtype=np.float32).reshape(3, 3)
+    frames[bad_at] = [(dists, R, np.array([t[0], np.nan, t[2]], dtype=np.float32), intr),
+                      (dists, R * np.array([[-1.0], [1.0], [1.0]], dtype=np.float32), t * np.array([-1, 1, 1], dtype=np.float32), intr),
+                      (dists, R, t, (-intr[0], intr[1], intr[2], intr[3]))][bad_at % 3]
+    start = rng.integers(0, 2 ** 32, size=64 * 48 * 40, dtype=np.uint64).astype(np.uint32)
+    h = (start & 0xFFFF).astype(np.uint16)
+    start = (start & 0xFFFF0000) | np.where((h & 0x7C00) == 0x7C00, h & 0xBBFF, h)
+    want = run_oracle(start, dims, vs, tr, synth.MAX_WEIGHT, frames)
+    got = run_batch(gpu_ctx, start, dims, vs, tr, synth.MAX_WEIGHT, frames)
+    assert np.count_nonzero(want != start) > 10000
+    assert np.array_equal(got, want), "%d voxel words differ" % np.count_nonzero(got != want)
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1), (2, 3), (1080, 1920)])
+def test_batch_image_sizes_from_one_pixel_to_full_hd(gpu_ctx, rows, cols):
+    rng = np.random.default_rng(rows + cols)
+    intr = (0.8 * max(cols, 8), 0.8 * max(cols, 8), cols / 2 - 0.5, rows / 2 - 0.5)
+    dims, vs, tr = synth.volume_geometry((56, 44, 48))
+    ex, ey = dims[0] * vs[0], dims[1] * vs[1]
+    frames = []
+    for k in range(3):
+        depth = (2000.0 + 150.0 * k + rng.normal(0, 3, (rows, cols))).clip(0, 65535).astype(np.uint16)
+        R = np.eye(3, dtype=np.float32)
+        t = np.array([-ex / 2 + 0.05 * k, -ey / 2, 0.8], dtype=np.float32)
+        frames.append((oracle.compute_dists(depth, intr), R, t, intr))
+    start = np.zeros(56 * 44 * 48, dtype=np.uint32)
+    want = run_oracle(start, dims, vs, tr, synth.MAX_WEIGHT, frames)
+    got = run_batch(gpu_ctx, start, dims, vs, tr, synth.MAX_WEIGHT, frames)
+    assert np.count_nonzero(want) > 0
+    assert np.array_equal(got, want), "%d voxel words differ" % np.count_nonzero(got != want)

@@ -606,3 +606,18 @@ def test_integrate_over_a_volume_of_arbitrary_words(gpu_ctx, kind):
     assert np.array_equal(hg[~nan_w], hw[~nan_w]), "%d finite tsdf values differ" % np.count_nonzero(hg[~nan_w] != hw[~nan_w])
     if kind == "finite halves, any weight":
         assert not nan_w.any() and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("intr", [(0.0, 525.0, 319.5, 239.5), (525.0, -525.0, 319.5, 239.5), (float("nan"), 525.0, 319.5, 239.5),
+                                  (525.0, 525.0, float("inf"), 239.5), (1e-30, 1e-30, 0.0, 0.0), (1e30, 1e30, 1e30, -1e30)])
+def test_compute_dists_degenerate_intrinsics(gpu_ctx, intr):
+    """Division by a zero focal length, NaN and infinite entries, overflow of the squared pixel offset: the half bit
+    patterns of imgproc.cu:259-283 in IEEE arithmetic, as the oracle computes them (NaN codes compared as NaN)."""
+    rng = np.random.default_rng(17)
+    depth = rng.integers(0, 65536, size=(37, 53), dtype=np.uint16)
+    depth[rng.random((37, 53)) < 0.2] = 0
+    want = oracle.compute_dists(depth, intr)
+    got = gpu_compute_dists(gpu_ctx, depth, intr)
+    nan = (want & 0x7FFF) > 0x7C00
+    assert np.array_equal((got & 0x7FFF) > 0x7C00, nan)
+    assert np.array_equal(got[~nan], want[~nan])
