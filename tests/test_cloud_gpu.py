@@ -135,3 +135,37 @@ def test_cloud_of_a_volume_of_arbitrary_finite_words(gpu_ctx, dims):
     got, _ = gpu_cloud(gpu_ctx, torch.from_numpy(vol.view(np.int32)).cuda(), dims, vs)
     assert len(got) == len(want) > 30
     assert np.array_equal(canon(got), canon(want))
+
+
+def test_normals_at_points_that_are_not_a_cloud(gpu_ctx):
+    """fetchNormals takes any points (tsdf_volume.cu:689-722): far outside the volume, on its faces, NaN and infinite
+    coordinates, over a volume of arbitrary finite words.  NaN where the oracle has NaN, its bits elsewhere."""
+    from test_mc_gpu import arbitrary_words
+
+    rng = np.random.default_rng(23)
+    dims, vs = (40, 33, 18), (0.01, 0.013, 0.009)
+    vol = arbitrary_words(dims, 41)
+    Rinv = np.ascontiguousarray(POSE_R.T)
+    ext = np.float32([dims[0] * vs[0], dims[1] * vs[1], dims[2] * vs[2]])
+    local = rng.uniform(-0.3, 1.3, size=(5000, 3)).astype(np.float32) * ext   # volume frame, a third of them outside
+    local[:200] = np.round(local[:200] / np.float32(vs)) * np.float32(vs)      # on voxel centres
+    local[200:260, 0] = 0.0
+    local[260:320, 2] = ext[2]
+    world = (local @ POSE_R.T + POSE_T).astype(np.float32)                    # pose: volume -> world (as extract_cloud maps)
+    world[320:330] = np.nan
+    world[330:335, 1] = np.inf
+    world[335:340] = np.float32(1e30)
+    pts = np.zeros((len(world), 4), dtype=np.float32)
+    pts[:, :3] = world
+    dev = torch.from_numpy(vol.view(np.int32)).cuda()
+    dpts = torch.from_numpy(pts).cuda()
+    nrm = torch.full((len(pts), 4), 7.0, dtype=torch.float32, device="cuda")
+    desc = capi.volume_desc(dev.data_ptr(), dims, vs, 0.04, 64)
+    gpu_ctx.extract_normals(desc, dpts.data_ptr(), len(pts), POSE_R.reshape(-1), POSE_T, Rinv.reshape(-1), nrm.data_ptr())
+    torch.cuda.synchronize()
+    want = oracle.extract_normals(vol, dims, vs, pts, POSE_R, POSE_T, Rinv)
+    got = nrm.cpu().numpy()
+    nan = np.isnan(want)
+    assert 100 < np.isnan(want[:, 0]).sum() < len(pts) - 100
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(got[~nan].view(np.uint32), want[~nan].view(np.uint32))
