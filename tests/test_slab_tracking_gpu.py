@@ -204,3 +204,36 @@ def test_icp_row_bands_sum_to_the_whole_image(gpu_ctx, world):
     assert (part == 0).all().item()
     with pytest.raises(capi.YakHipError):
         gpu_ctx.icp_accumulate_rows(Rg, tg, synth.INTR, 0, 0.1, 0.6, *args, rows, cols, 10, rows + 1, part.data_ptr())
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_raycasts_over_arbitrary_voxel_words_composite_to_the_whole(gpu_ctx, world):
+    """A volume that did not come from integrate: every sample pair may end the march, so every slab finds candidates
+    in its own layers and many winners defer their normal to a neighbour.  The composite must be the whole-volume ray
+    cast and the oracle's (NaN where they have NaN, the same bits elsewhere)."""
+    from test_mc_gpu import arbitrary_words
+
+    dims, vs, tr = synth.volume_geometry((48, 40, 56))
+    vol = arbitrary_words(dims, 77)
+    rows, cols, intr = 90, 120, (110.0, 110.0, 59.5, 44.5)
+    _, R_v2c, t_v2c = synth.scene_s2(200)
+    R, t = cam2vol(R_v2c, t_v2c)
+    Rinv = np.ascontiguousarray(R.T)
+    halo = capi.raycast_halo(capi.volume_desc(256, dims, vs, tr, synth.MAX_WEIGHT))
+    parts = []
+    for rank in range(world):
+        own = slab_range(dims[2], world, rank)
+        img, nrm, keys, slab = slab_raycast(gpu_ctx, vol, dims, vs, tr, own, halo, R, t, Rinv, intr, rows, cols)
+        w_img, w_nrm, w_keys = oracle.raycast_slab(vol, dims, vs, tr, R, t, Rinv, intr, rows, cols, own[0], own[1], nthreads=8)
+        k = keys.cpu().numpy()
+        assert np.array_equal(k & ~1, w_keys & ~1) and ((k == KEY_NONE) == (w_keys == KEY_NONE)).all()
+        parts.append((img, nrm, keys, slab))
+    c_img, c_nrm, best, n_odd = composite_on_one_gpu(gpu_ctx, parts, False, Rinv)
+    whole_p, whole_n = gpu_raycast(gpu_ctx, vol, dims, vs, tr, R, t, Rinv, intr, rows, cols)
+    o_p, o_n, _, hits = oracle.raycast(vol, dims, vs, tr, R, t, Rinv, intr, rows, cols, nthreads=8)
+    assert hits > 1000
+    for got, want in ((c_img, whole_p), (c_nrm, whole_n), (c_img, o_p), (c_nrm, o_n)):
+        g = got.cpu().numpy()
+        nan = np.isnan(want)
+        assert np.array_equal(np.isnan(g), nan)
+        assert np.array_equal(g[~nan].view(np.uint32), want[~nan].view(np.uint32))
