@@ -353,3 +353,69 @@ def test_surface_map_arguments(gpu_ctx):
     bad = capi.volume_desc(s.vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT, 3, 47, surface_map=s.map.data_ptr() + 2)
     with pytest.raises(capi.YakHipError):
         gpu_ctx.clear_volume(bad)                                 # misaligned map
+
+
+def test_rebuilt_map_of_a_sparse_uploaded_volume_changes_no_output(gpu_ctx):
+    """An uploaded volume that is free space (+1, weight 5) except for blobs of arbitrary finite words and single
+    voxels at brick corners -- negative values, -0.0, +0.0, denormals: most bricks stay unmarked, and what is next to a
+    brick boundary must still be seen.  Ray cast, marching cubes and cloud with the rebuilt map = without it."""
+    rng = np.random.default_rng(31)
+    dims = (96, 80, 112)
+    _, vs, tr = synth.volume_geometry(dims)
+    X, Y, Z = dims
+    vol = np.full((Z, Y, X), (5 << 16) | 0x3C00, dtype=np.uint32)
+    for _ in range(6):    # blobs of anything
+        cx, cy, cz = (int(rng.integers(8, n - 8)) for n in (X, Y, Z))
+        r = int(rng.integers(3, 8))
+        blob = rng.integers(0, 2 ** 32, size=(2 * r, 2 * r, 2 * r), dtype=np.uint64).astype(np.uint32)
+        h = (blob & 0xFFFF).astype(np.uint16)
+        blob = (blob & 0xFFFF0000) | np.where((h & 0x7C00) == 0x7C00, h & 0xBBFF, h)
+        vol[cz - r:cz + r, cy - r:cy + r, cx - r:cx + r] = blob
+    singles = [0xBC00, 0x8000, 0x0000, 0x8001, 0x0001, 0xB800, 0x8400]           # -1, -0, +0, -denormal, +denormal, -0.5, -2^-14
+    for k in range(60):   # single voxels on and next to brick corners and faces
+        bx, by, bz = (int(rng.integers(1, n // 16)) * 16 for n in (X, Y, Z))
+        dx, dy, dz = (int(v) for v in rng.integers(-1, 1, 3))
+        vol[bz + dz, by + dy, bx + dx] = (7 << 16) | singles[k % len(singles)]
+    vol = vol.reshape(-1)
+    s = Slab(dims, vs, tr)
+    s.vol.copy_(torch.from_numpy(vol.view(np.int32)).cuda())
+    gpu_ctx.surface_map_rebuild(s.desc)
+    bricks = s.bits()[:capi.surface_map_bytes(s.plain) // 4]
+    n_bricks = (X // 16) * (Y // 16) * (Z // 16)
+    marked = sum(bin(int(w)).count("1") for w in bricks[:(n_bricks + 31) // 32])
+    assert 10 < marked < n_bricks // 2, marked
+
+    rows, cols = 240, 320
+    intr = tuple(v / 2 for v in synth.INTR)
+    for view in (10, 130, 250):
+        _, R_v2c, t_v2c = synth.scene_s2(view)
+        R, t = cam2vol(R_v2c, t_v2c)
+        plain = raycast(gpu_ctx, s.plain, R, t, R_v2c, intr, rows, cols)
+        assert (~np.isnan(plain[0][..., 0])).sum() > 100
+        assert same_bits(raycast(gpu_ctx, s.desc, R, t, R_v2c, intr, rows, cols), plain)
+
+    def mesh(desc, min_weight):
+        n = gpu_ctx.marching_cubes(desc, min_weight, vs[0])
+        tri = torch.full((max(n, 1), 9), 7.0, dtype=torch.float32, device="cuda")
+        assert gpu_ctx.marching_cubes(desc, min_weight, vs[0], tri.data_ptr(), n) == n
+        return tri.cpu().numpy()[:n]
+
+    for min_weight in (0, 6):
+        plain_mesh = mesh(s.plain, min_weight)
+        assert len(plain_mesh) > 200
+        assert np.array_equal(mesh(s.desc, min_weight).view(np.uint32), plain_mesh.view(np.uint32))
+        want = oracle.marching_cubes(vol, dims, min_weight, vs[0])
+        assert len(want) == len(plain_mesh)
+
+    pose_R, pose_t = np.eye(3, dtype=np.float32).reshape(-1), np.zeros(3, dtype=np.float32)
+
+    def cloud(desc):
+        n = gpu_ctx.extract_cloud(desc, pose_R, pose_t)
+        pts = torch.full((max(n, 1), 4), 7.0, dtype=torch.float32, device="cuda")
+        assert gpu_ctx.extract_cloud(desc, pose_R, pose_t, pts.data_ptr(), n) == n
+        return pts.cpu().numpy()[:n]
+
+    plain_cloud = cloud(s.plain)
+    assert len(plain_cloud) > 200
+    assert np.array_equal(cloud(s.desc).view(np.uint32), plain_cloud.view(np.uint32))
+    assert len(oracle.extract_cloud(vol, dims, vs, np.eye(3, dtype=np.float32), pose_t)) == len(plain_cloud)
