@@ -259,3 +259,27 @@ def test_golden_fixture_s1_32():
     for _ in range(2):
         oracle.integrate(vol, dims, vs, tr, 64, dists, R, t, synth.INTR)
     assert np.array_equal(vol, g["vol_f3"])
+
+
+def test_oracle_rejects_nan_pixel_coordinates_instead_of_indexing_with_them():
+    """The stated deviation in integrate_column (oracle/yak_oracle.c): a NaN pixel coordinate -- non-finite pose or
+    intrinsics -- skips the voxel; the reference's __float2int_rd would turn it into 0 and read row / column 0.
+    (Before this was written out, the C restatement indexed the image with INT_MIN.)"""
+    import oracle
+    from yak_amd import synth
+
+    depth, R, t = synth.scene_s2(40)
+    dists = oracle.compute_dists(depth, synth.INTR)
+    dims, vs, tr = synth.volume_geometry((24, 20, 28))
+    R = np.asarray(R, dtype=np.float32).reshape(3, 3)
+    t = np.asarray(t, dtype=np.float32)
+    for R2, t2, intr in [(R, np.array([t[0], np.nan, t[2]], dtype=np.float32), synth.INTR),
+                         (np.where(np.eye(3) > 0, R, np.float32(np.nan)).astype(np.float32), t, synth.INTR),
+                         (R, t, (synth.INTR[0], synth.INTR[1], float("nan"), synth.INTR[3])),
+                         (R, t, (float("nan"), float("nan"), float("nan"), float("nan")))]:
+        vol = np.zeros(24 * 20 * 28, dtype=np.uint32)
+        _, updated = oracle.integrate(vol, dims, vs, tr, synth.MAX_WEIGHT, dists, R2, t2, intr)
+        assert updated == 0 and not vol.any()
+    vol = np.zeros(24 * 20 * 28, dtype=np.uint32)
+    _, updated = oracle.integrate(vol, dims, vs, tr, synth.MAX_WEIGHT, dists, R, t, synth.INTR)
+    assert updated > 0
