@@ -369,6 +369,8 @@ void TsdfVolume::raycast(const Affine3f& camera_pose, const Intr& intr, Cloud& p
 void TsdfVolume::raycastPyramid(const Affine3f& camera_pose, const Intr& intr, std::vector<Cloud>& points_pyr,
                                 std::vector<Normals>& normals_pyr, int levels)
 {
+  if (levels < 1 || (int)points_pyr.size() < levels || (int)normals_pyr.size() < levels)
+    ::kfusion::cuda::error("raycastPyramid: the pyramids hold fewer entries than `levels`", __FILE__, __LINE__, "raycastPyramid");
   Cloud& points = points_pyr[0];
   Normals& normals = normals_pyr[0];
   int done = 1;
