@@ -147,7 +147,7 @@ int main(int argc, char** argv)
       }
       kfusion::cuda::waitAllDefaultStream();  // (operator() returns before the device is done)
       t_loop = now();
-      volume = yak::TSDFContainer(n, n, n, yak::TSDFContainer::Uninitialized());  // overwritten by the download
+      volume = yak::TSDFContainer(n, n, n);
       kinfu.tsdf().data().download(volume.data());
       t_down = now();
     }
