@@ -73,18 +73,22 @@ PolygonMesh marchingCubesDevice(const void* volume_dev, int dim_x, int dim_y, in
     error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_weld_vertices");
   lap("allocate + weld");
   mesh.cloud.resize((size_t)nv);  // std::array<float, 3>: 12 contiguous bytes a point, as the device wrote them
-  std::vector<std::uint32_t> index(corners);
+  // the corner indices land in the polygon list itself (std::array<uint32_t, 3>: a triangle's three indices in a row)
+  // and the triangles with a repeated index are squeezed out in place: no second 12 MB buffer to fault in and fill
+  mesh.polygons.resize((size_t)n);
+  static_assert(sizeof(mesh.polygons[0]) == 3 * sizeof(std::uint32_t), "a polygon is three packed indices");
   if (yakhip_download(context(), mesh.cloud.data(), verts.ptr<void>(), (size_t)nv * 3 * sizeof(float)) != 0 ||
-      yakhip_download(context(), index.data(), index_dev.ptr<void>(), index.size() * sizeof(std::uint32_t)) != 0)
+      yakhip_download(context(), mesh.polygons.data(), index_dev.ptr<void>(), corners * sizeof(std::uint32_t)) != 0)
     error(yakhip_last_error(), __FILE__, __LINE__, "yakhip_download(weld)");
   lap("download vertices + indices");
-  mesh.polygons.reserve((size_t)n);
+  size_t kept = 0;
   for (size_t i = 0; i < (size_t)n; ++i)
   {
-    const std::uint32_t a = index[3 * i], b = index[3 * i + 1], c = index[3 * i + 2];
-    if (a != b && b != c && a != c)
-      mesh.polygons.push_back({ a, b, c });
+    const std::array<std::uint32_t, 3> tri = mesh.polygons[i];
+    if (tri[0] != tri[1] && tri[1] != tri[2] && tri[0] != tri[2])
+      mesh.polygons[kept++] = tri;
   }
+  mesh.polygons.resize(kept);
   lap("drop degenerate triangles");
   return mesh;
 }
