@@ -594,10 +594,19 @@ static void host_copy(uint8_t* dst, size_t dst_pitch, const uint8_t* src, size_t
   if (n_threads == 1)
     return part(0);
   std::thread helpers[3];
-  for (unsigned k = 1; k < n_threads; ++k)
-    helpers[k - 1] = std::thread(part, k);
+  unsigned started = 1;
+  try
+  {
+    for (; started < n_threads; ++started)
+      helpers[started - 1] = std::thread(part, started);
+  }
+  catch (...)  // no thread to be had: the caller does the parts that found none (nothing may be thrown across the C ABI)
+  {
+  }
   part(0);
-  for (unsigned k = 1; k < n_threads; ++k)
+  for (unsigned k = started; k < n_threads; ++k)
+    part(k);
+  for (unsigned k = 1; k < started; ++k)
     helpers[k - 1].join();
 }
 
