@@ -95,3 +95,29 @@ def test_static_entry_rejects_an_image_beyond_its_scratch(gpu_ctx):
     gpu_ctx.integrate(desc, dd.data_ptr(), cols * 2, rows, cols, np.eye(3).reshape(-1), np.zeros(3),
                       (500.0, 500.0, 512.0, 512.0))
     torch.cuda.synchronize()
+
+
+def test_static_entry_on_arbitrary_voxel_words_and_an_impossible_pose(gpu_ctx):
+    """The same words as yakhip_integrate where the volume did not come from integrate (any halves, any weights) and
+    where the culling tests switch themselves off (NaN in the pose, a negative focal length)."""
+    rng = np.random.default_rng(3)
+    dims, z0, z1, rows, cols = (64, 48, 40), 0, 40, 120, 160
+    voxel = 2.2 / (z0 + z1)
+    vs, tr = (voxel, voxel, voxel), max(0.06, 2.1 * voxel)
+    dists, intr = _frame(rows, cols, 9)
+    R, t = _pose(dims, vs)
+    start = rng.integers(0, 2 ** 32, size=dims[0] * dims[1] * (z1 - z0), dtype=np.uint64).astype(np.uint32)
+    h = (start & 0xFFFF).astype(np.uint16)
+    start = (start & 0xFFFF0000) | np.where((h & 0x7C00) == 0x7C00, h & 0xBBFF, h)
+    dd = torch.from_numpy(dists.view(np.int16)).cuda()
+    poses = [(R, t, intr), (R, np.array([t[0], np.nan, t[2]], dtype=np.float32), intr), (R, t, (-intr[0], intr[1], intr[2], intr[3]))]
+    out = {}
+    for entry in ("integrate", "integrate_static"):
+        vol = torch.from_numpy(start.view(np.int32)).cuda()
+        desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT, z0, z1)
+        for R2, t2, i2 in poses:
+            getattr(gpu_ctx, entry)(desc, dd.data_ptr(), cols * 2, rows, cols, R2.reshape(-1), t2, i2)
+        torch.cuda.synchronize()
+        out[entry] = vol.cpu().numpy().view(np.uint32).copy()
+    assert np.count_nonzero(out["integrate"] != start) > 1000
+    assert np.array_equal(out["integrate_static"], out["integrate"])
