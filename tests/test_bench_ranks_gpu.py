@@ -54,3 +54,18 @@ def test_one_rank_over_rccl():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["voxels_updated_per_step"] == 512 ** 3
     assert abs(d["value"] - 512 ** 3 / (d["ms_per_step"] * 1e-3) / 1e9) < 0.01 * d["value"]
+
+
+def test_cpp_loop_row_of_the_bench_line():
+    """bench.py's kinfu_loop row also reports the C++ host (examples/offline_fuse as a child process): the example must
+    be built and its output must parse."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    row = bench.cpp_loop_rates(120)
+    assert row is not None, "examples/offline_fuse missing or its output changed"
+    for key in ("fused_frames_per_s", "fused_frames_per_s_supplied_poses", "fused_frames_per_s_after_the_first_50",
+                "fused_frames_per_s_supplied_poses_after_the_first_50"):
+        assert row[key] > 100, (key, row)
