@@ -127,7 +127,12 @@ const char* yakhip_last_error(void);
  * "icp_poll" (0/1: yakhip_icp_estimate polls pinned memory for its result / copies and
  * synchronises), "surface_skip" (0/1: the ray cast consults / ignores yakhip_volume.surface_map),
  * "brick_stats" (0/1, see yakhip_ctx_brick_stats), "composite_capacity" (list slots of yakhip_raycast_sharded's second step, 0 = auto),
- * "zu" (ignored).
+ * "defer_mixed" (how yakhip_integrate launches: 0 one kernel, every workgroup walking its own bricks; 2 two kernels wherever the
+ * 16-byte layout allows -- the brick test for the whole grid first, then the live bricks' parts dealt out evenly to a fixed number
+ * of workgroups; 1, the default, one or the other by what the brick test found in the last frames of this volume, see
+ * yakhip_ctx_launch_counts), "mixed_waves" (workgroups per CU of the second kernel, 0 = auto), "refine" (0/1: the second kernel
+ * tests a part again layer by layer before walking it),
+ * "zu" (ignored).  The environment variable YAK_HIP_DEFER_MIXED (0/1/2) sets "defer_mixed" for every new context.
  * Unknown key or value -> YAKHIP_EINVAL. */
 int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value);
 /* Measurement aid with no counterpart in the reference (its only timers are the never-invoked
@@ -146,6 +151,9 @@ int yakhip_ctx_kernel_times(yakhip_ctx* ctx, float* ms_out, float* start_ms_out,
  * this call waits, returns counts = {dead (no voxel can update: skipped), front (every voxel updates with
  * tsdf 1: streamed), mixed (walked voxel by voxel)} since the last call and restarts the count. */
 int yakhip_ctx_brick_stats(yakhip_ctx* ctx, unsigned long long counts[3]);
+/* Measurement aid, no counterpart in the reference: counts = {yakhip_integrate launches of this context that ran as one
+ * kernel, ... as two kernels} since the context was created ("defer_mixed" above; the voxels are the same either way). */
+int yakhip_ctx_launch_counts(yakhip_ctx* ctx, unsigned long long counts[2]);
 /* Device self-test with no counterpart in the reference: the integrate kernel replaces IEEE '/' by a
  * v_rcp_f32 + Newton + Markstein sequence; this checks on the GPU at hand that (a) the refined
  * reciprocal is the correctly rounded 1/d for all 2^23 mantissas at 8 exponents and (b) the quotient

@@ -147,3 +147,36 @@ def test_an_image_rewritten_through_the_library_is_not_taken_from_what_was_prepa
         torch.cuda.synchronize()
         assert np.count_nonzero(want >> 16) > 0
         assert np.array_equal(got, want), "%s: %d voxel words differ" % (how, np.count_nonzero(got != want))
+
+
+def test_a_prepass_ahead_of_time_waits_for_the_walk_that_still_reads_its_half_of_the_scratch(gpu_ctx):
+    """prepare(A), integrate(B) -- B's own prepass goes to the first half of the scratch and its walk reads
+    it --, then, on the side stream, prepare(C) into that same half while the walk may still be running, integrate(C).
+    The same after a batch, whose frames lie across both halves.  A long walk (a large volume) to give the race room."""
+    dims, z0, z1, rows, cols = (256, 256, 192), 0, 192, 480, 640
+    vs, tr, intr, R, t, da, db = _setup(dims, z0, z1, rows, cols)
+    c, _ = _frame(rows, cols, 9, 0.4)
+    dc = torch.from_numpy(c.view(np.int16)).cuda()
+    args = lambda d: (d.data_ptr(), cols * 2, rows, cols, R.reshape(-1), t, intr)  # noqa: E731
+    pre = lambda desc, d: gpu_ctx.integrate_prepare(desc, d.data_ptr(), cols * 2, rows, cols)  # noqa: E731
+
+    for batch in (False, True):
+        vol, desc = _volume(dims, vs, tr, z0, z1)
+        for _ in range(3):
+            for d in (db, da, dc) if batch else (db, dc):
+                gpu_ctx.integrate(desc, *args(d))
+        want = _words(vol)
+        vol, desc = _volume(dims, vs, tr, z0, z1)
+        for _ in range(3):
+            pre(desc, da)                        # never taken up
+            if batch:
+                gpu_ctx.integrate_batch(desc, [args(db), args(da)])
+            else:
+                gpu_ctx.integrate(desc, *args(db))
+            gpu_ctx.side_begin()
+            pre(desc, dc)
+            gpu_ctx.side_end()
+            gpu_ctx.integrate(desc, *args(dc))
+        got = _words(vol)
+        assert np.count_nonzero(want >> 16) > 0
+        assert np.array_equal(got, want), "batch=%s: %d voxel words differ" % (batch, np.count_nonzero(got != want))

@@ -35,19 +35,25 @@ def main():
     s0, s1 = frame(*synth.scene_s0()), frame(*synth.scene_s1())
     views = [frame(*synth.scene_s2(f, noise_mm=1.0)) for f in range(0, 300, 38)]
 
+    sync = "--no-sync" not in sys.argv
+
     def timed(frames, reps):
         for a in frames:
             ctx.integrate(desc, *a)
+            if sync:
+                torch.cuda.synchronize()
         ctx.set_option("kernel_timing", 1)
         for _ in range(reps):
             for a in frames:
                 ctx.integrate(desc, *a)
+                if sync:
+                    torch.cuda.synchronize()  # (one wait per frame, as a tracking loop has: the launcher's hint stays fresh)
         ms, _ = ctx.kernel_times(reps * len(frames))
         ctx.set_option("kernel_timing", 0)
         return [sum(ms[i::len(frames)]) / reps for i in range(len(frames))]
 
     orbit_only = "--orbit" in sys.argv
-    settings = [a for a in sys.argv[1:] if a != "--orbit"] or [""]
+    settings = [a for a in sys.argv[1:] if a not in ("--orbit", "--no-sync")] or [""]
     defaults = {"tile": 0, "chunk_order": -1, "brick_test": 1, "group_test": 1, "tile_side": 1, "defer_mixed": 1, "refine": 1}
     # warm the board (bench.py: launches right after idle run slow)
     for _ in range(60):

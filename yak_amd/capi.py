@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libyakhip.so")
 EXPORTS = [
     "yakhip_ctx_create", "yakhip_ctx_destroy", "yakhip_ctx_set_stream", "yakhip_ctx_use_own_stream", "yakhip_ctx_synchronize",
     "yakhip_device_count", "yakhip_device_name", "yakhip_last_error", "yakhip_ctx_set_option", "yakhip_ctx_side_begin", "yakhip_ctx_side_end", "yakhip_ctx_stream",
-    "yakhip_ctx_kernel_time", "yakhip_ctx_kernel_times", "yakhip_ctx_brick_stats", "yakhip_selftest_division",
+    "yakhip_ctx_kernel_time", "yakhip_ctx_kernel_times", "yakhip_ctx_brick_stats", "yakhip_ctx_launch_counts", "yakhip_selftest_division",
     "yakhip_malloc", "yakhip_malloc_pitch", "yakhip_free", "yakhip_upload", "yakhip_download",
     "yakhip_upload_2d", "yakhip_download_2d", "yakhip_copy", "yakhip_copy_2d",
     "yakhip_clear_volume", "yakhip_surface_map_bytes", "yakhip_surface_map_rebuild", "yakhip_compute_dists", "yakhip_integrate", "yakhip_integrate_static",
@@ -104,6 +104,7 @@ def load():
         "yakhip_ctx_kernel_time": [vp, C.POINTER(C.c_double), C.POINTER(i)],
         "yakhip_ctx_kernel_times": [vp, fp, fp, i, C.POINTER(i)],
         "yakhip_ctx_brick_stats": [vp, C.POINTER(C.c_ulonglong)],
+        "yakhip_ctx_launch_counts": [vp, C.POINTER(C.c_ulonglong)],
         "yakhip_selftest_division": [vp, C.POINTER(C.c_ulonglong)],
         "yakhip_malloc": [vp, C.POINTER(vp), sz],
         "yakhip_malloc_pitch": [vp, C.POINTER(vp), C.POINTER(sz), sz, sz],
@@ -240,6 +241,12 @@ class Context:
         out = (C.c_ulonglong * 3)()
         _chk(load().yakhip_ctx_brick_stats(self._h, out))
         return {"dead": int(out[0]), "front": int(out[1]), "mixed": int(out[2])}
+
+    def launch_counts(self):
+        """{one_kernel, two_kernels}: how this context's yakhip_integrate launches ran so far ("defer_mixed" option)."""
+        out = (C.c_ulonglong * 2)()
+        _chk(load().yakhip_ctx_launch_counts(self._h, out))
+        return {"one_kernel": int(out[0]), "two_kernels": int(out[1])}
 
     def selftest_division(self):
         out = (C.c_ulonglong * 4)()

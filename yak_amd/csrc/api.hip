@@ -2,6 +2,7 @@
 // device memory, and dispatch to the kernel launchers.  No kernels here.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <thread>
@@ -149,6 +150,25 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->ckpt_bytes = 0;
   ctx->static_scratch = nullptr;
   ctx->brick_stats = nullptr;
+  ctx->classes = nullptr;
+  ctx->classes_bytes = 0;
+  ctx->classes_n = 0;
+  ctx->stats_host = nullptr;
+  ctx->launch_seq = ctx->classes_seq = 0;
+  ctx->launches_one = ctx->launches_two = 0;
+  ctx->cptab = nullptr;
+  ctx->cptab_bytes = 0;
+  ctx->defer_mixed = 1;
+  if (const char* e = getenv("YAK_HIP_DEFER_MIXED"))  // (tuning / tests: 0 never, 1 large launches, 2 every launch)
+    if (e[0] >= '0' && e[0] <= '2' && e[1] == 0)
+      ctx->defer_mixed = e[0] - '0';
+  ctx->mixed_waves = 0;
+  ctx->refine = 1;
+  ctx->num_cus = 0;
+  ctx->thr_read[0] = ctx->thr_read[1] = nullptr;
+  ctx->prepare_used = 0;
+  ctx->thr_read_valid[0] = ctx->thr_read_valid[1] = 0;
+  ctx->thr_slot_read = -1;
   ctx->icp_scratch = nullptr;
   ctx->icp_scratch_bytes = 0;
   ctx->icp_pinned = nullptr;
@@ -185,6 +205,16 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
     delete ctx;
     return rc;
   }
+  if (hipHostMalloc((void**)&ctx->stats_host, 64, hipHostMallocDefault) == hipSuccess)
+    memset(ctx->stats_host, 0, 64);
+  else
+    ctx->stats_host = nullptr;  // (then every large launch is one kernel, as before)
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0)
+      cus = 256;
+    ctx->num_cus = cus;
+  }
   *out = ctx;
   return 0;
 }
@@ -203,6 +233,15 @@ int yakhip_ctx_destroy(yakhip_ctx* ctx)
       (void)hipFree(ctx->ckpt);
     if (ctx->brick_stats)
       (void)hipFree(ctx->brick_stats);
+    if (ctx->classes)
+      (void)hipFree(ctx->classes);
+    if (ctx->stats_host)
+      (void)hipHostFree(ctx->stats_host);
+    if (ctx->cptab)
+      (void)hipFree(ctx->cptab);
+    for (int i = 0; i < 2; ++i)
+      if (ctx->thr_read[i])
+        (void)hipEventDestroy(ctx->thr_read[i]);
     if (ctx->icp_scratch)
       (void)hipFree(ctx->icp_scratch);
     if (ctx->icp_pinned)
@@ -403,6 +442,25 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
     ctx->checkpoint = value != 0;
     return 0;
   }
+  if (strcmp(key, "defer_mixed") == 0)
+  {
+    if (value < 0 || value > 2)
+      return fail(YAKHIP_EINVAL, "defer_mixed must be 0 (never), 1 (large launches) or 2 (every launch with the brick test)");
+    ctx->defer_mixed = value;
+    return 0;
+  }
+  if (strcmp(key, "mixed_waves") == 0)
+  {
+    if (value < 0 || value > 8)
+      return fail(YAKHIP_EINVAL, "mixed_waves must be 0 (default) or 1..8");
+    ctx->mixed_waves = value;
+    return 0;
+  }
+  if (strcmp(key, "refine") == 0)
+  {
+    ctx->refine = value != 0;
+    return 0;
+  }
   if (strcmp(key, "tile") == 0)
   {
     if (value != 0 && (value < 3 || value > 6))
@@ -478,6 +536,15 @@ int yakhip_ctx_kernel_times(yakhip_ctx* ctx, float* ms_out, float* start_ms_out,
   }
   *launches = (int)ctx->timing_used;
   ctx->timing_used = 0;
+  return 0;
+}
+
+int yakhip_ctx_launch_counts(yakhip_ctx* ctx, unsigned long long counts[2])
+{
+  if (!ctx || !counts)
+    return fail(YAKHIP_EINVAL, "launch_counts: null context or out pointer");
+  counts[0] = ctx->launches_one;
+  counts[1] = ctx->launches_two;
   return 0;
 }
 

@@ -38,10 +38,21 @@
 namespace yakhip
 {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kDefaultTileShift = 6;  // wave footprint in a layer, see lane_voxels()
+constexpr int kMixedWavesPerSimd = 5;  // size of integrate_list_kernel's grid: workgroups per CU
+constexpr uint32_t kDeferMinWaves = 8192;  // launches of fewer wave bricks than this walk their mixed bricks in place
+constexpr int kPartLayers = 8;         // a listed brick is walked in parts of this many layers (at most four parts)
+constexpr int kCheckpointStride = 32;  // layers between the column checkpoints of a launch with a list
+// layers per part of a brick of `layers` layers: kPartLayers, or what makes four parts of a longer brick (even)
+__host__ __device__ inline int part_layers(int layers)
+{
+  const int quarter = (((layers + 3) >> 2) + 1) & ~1;
+  return quarter > kPartLayers ? quarter : kPartLayers;
+}
 
 template <int VX>
 struct Vec;
@@ -193,6 +204,9 @@ __device__ __forceinline__ f32x2 band_thresholds(float Dp, float trunc_hi)
 // and the integrate kernels start from that.
 constexpr int kCheckpointFrom = 64;  // slabs starting below this layer replay from 0 as before
 constexpr int kBrickCell = 16;       // pixels per side of a brick-test cell (prepass_kernel, classify_brick)
+constexpr int kFineShift = 2;        // ... and of the cells a mixed brick's pieces are tested against: 4 x 4 pixels
+constexpr int kFineCell = 1 << kFineShift;
+constexpr int kFineMaxCells = 64;    // a pixel box of more fine cells than this is looked up in the 16-pixel cells
 
 __device__ __forceinline__ void checkpoint_column(const IntegrateParams& p, float* out, uint32_t col)
 {
@@ -221,7 +235,9 @@ __global__ __launch_bounds__(256) void prepass_kernel(const uint8_t* dists, uint
                                                       int bk, uint32_t thr_blocks_x, uint32_t thr_blocks,
                                                       uint32_t ckpt_blocks, const IntegrateParams cp,
                                                       float* ckpt_out, float* cellmin, float* cellmax, int ccw, int cch,
-                                                      uint32_t coarse_blocks)
+                                                      uint32_t coarse_blocks, uint32_t brick_blocks, uint32_t fine_blocks,
+                                                      const uint32_t* prev_classes, uint32_t prev_bricks, uint32_t prev_seq,
+                                                      uint32_t* stats_out)
 {
   // the column checkpoints of a deep slab are the long job of this launch: its workgroups come first, the
   // image's fill in behind them (ckpt_blocks = 0 for a slab that replays from layer 0)
@@ -245,9 +261,73 @@ __global__ __launch_bounds__(256) void prepass_kernel(const uint8_t* dists, uint
     if (ab.y >= 0.f)
       ab.y = __uint_as_float(((__float_as_uint(ab.y) + 0xffffu) & 0xffff0000u) | bits);
     thr[(size_t)y * cols + x] = ab;
+    if (x == 0 && y == 0)  // the entry behind the image: what a voxel that sees no pixel gathers (IntegrateParams::thr_none)
+      thr[(size_t)rows * cols] = f32x2{ -1.f, -1.f };
     return;
   }
   const int lane = (int)(threadIdx.x & 63u);
+  if (bid >= thr_blocks + coarse_blocks + brick_blocks + fine_blocks)
+  {
+    // One more workgroup, when the launcher asks for it: what the PREVIOUS launch's brick test found -- front and mixed
+    // wave bricks, from the class bytes it left -- written to pinned host memory, where the launcher reads it (whenever
+    // it gets there: a hint) to choose between the one-kernel and the two-kernel launch for a later frame.
+    const uint32_t groups = (prev_bricks + 1023u) >> 10;
+    uint32_t front = 0, live = 0;
+    for (uint32_t i = 0; i < groups; ++i)
+    {
+      const uint32_t w = prev_classes[i * 256u + threadIdx.x];
+      front += (uint32_t)__builtin_popcount(w & 0x80808080u);
+      const uint32_t u = w & 0x07070707u;
+      live += (uint32_t)__builtin_popcount((u | (u >> 1) | (u >> 2)) & 0x01010101u);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+    {
+      front += __shfl_xor(front, off);
+      live += __shfl_xor(live, off);
+    }
+    __shared__ uint32_t part[2][4];
+    if (lane == 0)
+      part[0][threadIdx.x >> 6] = front, part[1][threadIdx.x >> 6] = live;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+      front = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+      live = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+      __builtin_nontemporal_store(front, stats_out + 0);
+      __builtin_nontemporal_store(live - front, stats_out + 1);
+      __builtin_nontemporal_store(prev_bricks, stats_out + 2);
+      __builtin_nontemporal_store(prev_seq, stats_out + 3);  // (last: the launcher takes the four words as they are)
+    }
+    return;
+  }
+  if (bid >= thr_blocks + coarse_blocks + brick_blocks)
+  {
+    // the brick test's planes once more over kFineCell x kFineCell pixel cells (one lane per cell): what the second
+    // kernel tests the pieces of a mixed brick against (cp.finemin / cp.finemax, cp.fcw x cp.fch cells)
+    const int c = (int)(bid - thr_blocks - coarse_blocks - brick_blocks) * 256 + (int)threadIdx.x;
+    if (c >= cp.fcw * cp.fch)
+      return;
+    const int cx = c % cp.fcw, cy = c / cp.fcw;
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    for (int j = 0; j < kFineCell; ++j)
+      for (int i = 0; i < kFineCell; ++i)
+      {
+        const int x = kFineCell * cx + i, y = kFineCell * cy + j;
+        if (x < cols && y < rows)
+        {
+          const uint32_t bits = *(const uint16_t*)(dists + (size_t)y * dists_pitch + (size_t)x * 2u);
+          f32x2 ab = band_thresholds(half_bits_to_float(bits), trunc_hi);
+          if (ab.y >= 0.f)  // the word the kernel compares d2 with, as below
+            ab.y = __uint_as_float(((__float_as_uint(ab.y) + 0xffffu) & 0xffff0000u) | bits);
+          lo = __builtin_fminf(lo, ab.x);
+          hi = __builtin_fmaxf(hi, ab.y);
+        }
+      }
+    const_cast<float*>(cp.finemin)[c] = lo;
+    const_cast<float*>(cp.finemax)[c] = hi;
+    return;
+  }
   if (bid >= thr_blocks + coarse_blocks)
   {
     // brick test planes: min A2 / max B2 word over the pixels of each kBrickCell x kBrickCell cell (one wave per
@@ -305,7 +385,70 @@ __global__ __launch_bounds__(256) void prepass_kernel(const uint8_t* dists, uint
     coarse[cell] = m;
 }
 
+#ifdef YAK_INTEGRATE_TIMING
+// diagnostic build only (make EXTRA=-DYAK_INTEGRATE_TIMING; tools/bench_orbit_waves.py): per wave brick of the last launch
+// {class + 1, shader-clock cycles in all, cycles to the end of the brick test, replay cycles,
+//  layers walked | duration in 10 ns ticks << 16, (HW_ID | XCC << 16) << 40 | start on the device-wide 100 MHz clock}
+constexpr int kItSlots = 1 << 17;
+__device__ unsigned long long g_it_time[kItSlots][6];
+// ... and per walked brick, shader-clock cycles spent in {stage 1, settle, the wait for voxels the look-ahead did not bring,
+// fuse, store + look-ahead}, then the number of {such waits, layers that took the per-voxel path, layers with band voxels}
+__device__ unsigned long long g_it_phase[kItSlots][8];
+struct ItPhase
+{
+  unsigned long long t[8];
+};
+#define IT_CLOCK(var) var = __builtin_readcyclecounter()
+#define IT_PHASE_PARAM , ItPhase& itp
+#define IT_PHASE_ARG , itp
+#define IT_LAP(i)                                              \
+  do                                                           \
+  {                                                            \
+    const unsigned long long it_n = __builtin_readcyclecounter(); \
+    itp.t[i] += it_n - it_lap;                                 \
+    it_lap = it_n;                                             \
+  } while (0)
+#define IT_LAP_START unsigned long long it_lap = __builtin_readcyclecounter()
+#define IT_COUNT(i, cond) itp.t[i] += (cond) ? 1 : 0
+#define IT_BEGIN                                                        \
+  unsigned long long it_t0, it_t1 = 0, it_t3 = 0;                       \
+  const unsigned long long it_r0 = __builtin_amdgcn_s_memrealtime();    \
+  IT_CLOCK(it_t0)
+#define IT_ROW(slot_, cls_, t_cls_, t_replay_, layers_)                                                                  \
+  do                                                                                                                     \
+  {                                                                                                                      \
+    if ((threadIdx.x & 63u) == 0)                                                                                        \
+    {                                                                                                                    \
+      unsigned hw, xcc;                                                                                                  \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                                   \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                                                 \
+      hw = (hw & 0xffffu) | ((xcc & 0xfu) << 16);                                                                        \
+      unsigned long long* row = g_it_time[(size_t)(slot_) & (kItSlots - 1)];                                             \
+      const unsigned long long it_now = __builtin_readcyclecounter();                                                    \
+      row[0] = (unsigned long long)(cls_) + 1, row[1] = it_now - it_t0, row[2] = (t_cls_) - it_t0, row[3] = (t_replay_); \
+      row[4] = (unsigned long long)(layers_) | ((__builtin_amdgcn_s_memrealtime() - it_r0) << 16);                       \
+      row[5] = ((unsigned long long)hw << 40) | (it_r0 & 0xffffffffffull);                                               \
+    }                                                                                                                    \
+  } while (0)
+#else
+#define IT_CLOCK(var)
+#define IT_BEGIN
+#define IT_ROW(slot_, cls_, t_cls_, t_replay_, layers_)
+#define IT_PHASE_PARAM
+#define IT_PHASE_ARG
+#define IT_LAP(i)
+#define IT_LAP_START
+#define IT_COUNT(i, cond)
+#endif
+
 // ---- the kernel ------------------------------------------------------------------------------------
+// What the brick test (classify_box below) says of a box of voxels.
+enum BrickClass
+{
+  kBrickMixed = 0,
+  kBrickDead = 1,
+  kBrickFront = 2
+};
 // Per-lane predicates are kept as 64-bit wave masks in SGPRs (ballot / inverse ballot): combining
 // them is scalar work, and a rare case anywhere in the wave is one scalar branch.
 typedef unsigned long long mask_t;
@@ -330,10 +473,11 @@ struct Pos
 template <int VX>
 struct Probe
 {
-  f32x2 ab[VX];       // gathered {A2, B2} thresholds of the pixel each voxel sees
+  f32x2 ab[VX];       // gathered {A2, B2} thresholds of the pixel each voxel sees; {-1, -1} ("never in front, always
+                      // behind", what a pixel without a return has) for a voxel that projects outside the image or
+                      // whose vc.z is outside the Markstein range: no mask per voxel has to travel with them
   float d2[VX];       // dot(vc, vc)
-  mask_t inside[VX];  // projects into the image (and vc.z is in the Markstein range)
-  mask_t slow[VX];    // vc.z outside [2^-20, 2^20]: only measure_exact() can decide
+  mask_t slow_any;    // lanes with a voxel whose vc.z is outside [2^-20, 2^20]: only measure_exact() can decide it
   mask_t pass;        // lanes whose whole voxel run was settled by the group test (all VX voxels hit, tsdf 1)
   bool detailed;      // wave-uniform: the per-voxel fields above were produced for this layer
 };
@@ -367,11 +511,10 @@ __device__ __forceinline__ void project(const IntegrateParams& p, const Pos<VX>&
       const uint32_t px = (uint32_t)floor_to_int(coox[h]), py = (uint32_t)floor_to_int(cooy[h]);
       // :83 -- floor(coo) inside the image <=> 0 <= coo < size
       const mask_t inside = fast & ballot(px < (uint32_t)p.cols) & ballot(py < (uint32_t)p.rows);
-      const uint32_t idx = lanes(inside) ? __umul24(py, (uint32_t)p.cols) + px : 0u;
+      const uint32_t idx = lanes(inside) ? __umul24(py, (uint32_t)p.cols) + px : p.thr_none;
       o.ab[v] = p.thr[idx];
       o.d2[v] = d2[h];
-      o.inside[v] = inside;
-      o.slow[v] = ~fast;
+      o.slow_any |= ~fast;
     }
   }
 }
@@ -407,19 +550,32 @@ __device__ __forceinline__ mask_t group_test(const IntegrateParams& p, f32x2 x, 
 }
 
 // Stage 1 of one layer: group test first; the exact per-voxel projection only if some lane needs it.
+// lcls (wave-uniform): what is already known of this layer of the wave's brick -- kBrickDead: no voxel of it can take
+// an update, kBrickFront: every voxel takes one with tsdf 1 (classify_pieces); neither needs a projection.
 template <int VX>
 __device__ __forceinline__ void stage1(const IntegrateParams& p, const Pos<VX>& c, Probe<VX>& o,
                                        const float* coarse_lds, mask_t active, f32x2 fx2, f32x2 fy2, f32x2 cx2,
-                                       f32x2 cy2)
+                                       f32x2 cy2, int lcls = kBrickMixed)
 {
+  if (lcls != kBrickMixed)
+  {
+    o.detailed = false;
+    o.pass = lcls == kBrickFront ? active : 0;
+    o.slow_any = 0;
+    return;
+  }
   mask_t pass = 0;
   if constexpr (VX == 4)
     if (p.grp_enable)
       pass = group_test(p, c.x[0], c.y[0], c.z[0], coarse_lds, fx2, fy2, cx2, cy2);
   o.detailed = (active & ~pass) != 0;
   o.pass = o.detailed ? 0 : pass;
+  o.slow_any = 0;
   if (o.detailed)
+  {
     project<VX>(p, c, o, fx2, fy2, cx2, cy2);
+    o.slow_any &= active;
+  }
 }
 
 template <int VX>
@@ -480,9 +636,10 @@ __device__ __forceinline__ void buf_store(typename Vec<VX>::type v, rsrc_t rs, u
 // Decide every voxel of a lane's run at one layer from what stage 1 left: which voxels take an update
 // (hit), which of those with a measurement of exactly 1.0 (unit), and the measurement (tsdf).
 template <int VX>
-__device__ __forceinline__ void settle(const IntegrateParams& p, const Pos<VX>& c, const Probe<VX>& pr, mask_t live_m,
+__device__ __forceinline__ void settle(const IntegrateParams& p, const Pos<VX>& c, const Probe<VX>& pr, mask_t live_in,
                                        mask_t (&hit)[VX], mask_t (&unit)[VX], float (&tsdf)[VX], mask_t& negative)
 {
+  const mask_t live_m = live_in & ballot(true);  // (lanes that own no voxels are not part of any mask)
 #pragma unroll
   for (int v = 0; v < VX; ++v)
   {
@@ -496,48 +653,49 @@ __device__ __forceinline__ void settle(const IntegrateParams& p, const Pos<VX>& 
 #pragma unroll
     for (int v = 0; v < VX; ++v)
     {
-      const mask_t front = pr.inside[v] & ballot(pr.d2[v] <= pr.ab[v].x) & live_m;
+      // (a voxel outside the image, or one only measure_exact() can decide, carries {-1, -1}: not in front, and
+      //  behind unless its d2 is a NaN -- then the band path below finds a ray length of 0 and no update)
+      const mask_t front = ballot(pr.d2[v] <= pr.ab[v].x) & live_m;
       const mask_t behind = ballot(pr.d2[v] > pr.ab[v].y);
       hit[v] = front;
       unit[v] = front;
-      rare[v] = ((pr.inside[v] & ~front & ~behind) | pr.slow[v]) & live_m;
+      rare[v] = ~front & ~behind & live_m;
       rare_any |= rare[v];
     }
+    rare_any |= pr.slow_any & live_m;
     if (rare_any != 0)  // wave-uniform branch
     {
       // Inside the truncation band the reference's expression is evaluated as written (tsdf_volume.cu:92-96)
       // on what stage 1 already holds: d2 = dot(vc, vc) bit for bit, and the pixel's ray length in the low
       // half of the threshold word.  Straight-line for all VX voxels; the masks pick the lanes it is for.
-      mask_t slow_any = 0;
 #pragma unroll
       for (int v = 0; v < VX; ++v)
       {
-        const mask_t band = rare[v] & ~pr.slow[v];
         const float Dp = half_bits_to_float(__float_as_uint(pr.ab[v].y) & 0xffffu);
         const float sdf = Dp - __builtin_sqrtf(pr.d2[v]);
         const float t = __builtin_fminf(1.f, sdf * p.trunc_inv);
-        const mask_t in_band = band & ballot(sdf >= -p.trunc);
+        const mask_t in_band = rare[v] & ballot(sdf >= -p.trunc);
         tsdf[v] = lanes(in_band) ? t : tsdf[v];
         hit[v] |= in_band;
         unit[v] |= in_band & ballot(t == 1.f);
         negative |= in_band & ballot(t < 0.f);  // (surface map: the only way a voxel turns negative)
-        slow_any |= rare[v] & pr.slow[v];
       }
-      if (slow_any != 0)  // wave-uniform: vc.z outside the Markstein range, practically never
+      if ((pr.slow_any & live_m) != 0)  // wave-uniform: vc.z outside the Markstein range, practically never
       {
         // Masks are wave-wide values: they may only be updated in wave-uniform control flow.  Inside
         // the per-lane regions below only per-lane variables change; the ballots come after the join.
+        // (Such a voxel carries {-1, -1}, so the band path above found a ray length of 0 for it and left it alone.)
         bool exact_hit[VX];
 #pragma unroll
         for (int v = 0; v < VX; ++v)
         {
           exact_hit[v] = false;
-          if (lanes(rare[v] & pr.slow[v]))
+          const float vz = c.z[Pos<VX>::pair_of(v)][Pos<VX>::half_of(v)];
+          if (!in_div_range(vz) && lanes(live_m))
           {
             float t = 1.f;
             exact_hit[v] = measure_exact(p, c.x[Pos<VX>::pair_of(v)][Pos<VX>::half_of(v)],
-                                         c.y[Pos<VX>::pair_of(v)][Pos<VX>::half_of(v)],
-                                         c.z[Pos<VX>::pair_of(v)][Pos<VX>::half_of(v)], t);
+                                         c.y[Pos<VX>::pair_of(v)][Pos<VX>::half_of(v)], vz, t);
             tsdf[v] = exact_hit[v] ? t : tsdf[v];
           }
         }
@@ -591,13 +749,16 @@ template <int VX, bool NT>
 __device__ __forceinline__ void update(const IntegrateParams& p, const Pos<VX>& c, const Probe<VX>& pr,
                                        typename Vec<VX>::type& buf, mask_t& buf_valid, rsrc_t rs, uint32_t voff,
                                        uint32_t soff, uint32_t layer_bytes, bool live, bool ahead_ok,
-                                       uint32_t max_w_hi, mask_t& band)
+                                       uint32_t max_w_hi, mask_t& band IT_PHASE_PARAM)
 {
   typedef typename Vec<VX>::type vec_t;
   mask_t hit[VX], unit[VX];
   float tsdf[VX];
   mask_t hit_any = 0;
+  IT_LAP_START;
+  IT_COUNT(6, pr.detailed);
   settle<VX>(p, c, pr, live ? ~0ull : 0ull, hit, unit, tsdf, band);
+  IT_LAP(1);
 #pragma unroll
   for (int v = 0; v < VX; ++v)
     hit_any |= hit[v];
@@ -605,6 +766,7 @@ __device__ __forceinline__ void update(const IntegrateParams& p, const Pos<VX>& 
   // the reference reads only updated voxels (tsdf_volume.cu:98-100): demand-load what the look-ahead
   // did not bring (first two layers of a chunk, and lanes whose updates start at this layer)
   const mask_t need = hit_any & ~buf_valid;
+  IT_COUNT(5, need != 0);
   if (need != 0)  // wave-uniform, rare after the first trips
   {
     const vec_t got = buf_load<VX, NT>(rs, lanes(need) ? voff : kNoAccess, soff);
@@ -614,8 +776,10 @@ __device__ __forceinline__ void update(const IntegrateParams& p, const Pos<VX>& 
       vset<VX>(buf, v, lanes(need) ? vget<VX>(got, v) : vget<VX>(buf, v));
   }
 
+  IT_LAP(2);
   vec_t out = buf;
   fuse_run<VX>(buf, out, hit, unit, tsdf, p.max_weight, max_w_hi);
+  IT_LAP(3);
   // (an access that is switched off for the whole wave -- a layer past the chunk's end -- also gets a scalar
   // offset inside the descriptor: voffset 2^31 is then out of range whether the hardware compares
   // voffset >= num_records - soffset or voffset + soffset >= num_records)
@@ -625,6 +789,7 @@ __device__ __forceinline__ void update(const IntegrateParams& p, const Pos<VX>& 
   // update the layer two steps on (this buffer's next use); fetch it now
   buf_valid = ahead_ok ? hit_any : 0;
   buf = buf_load<VX, NT>(rs, lanes(buf_valid) ? voff : kNoAccess, ahead_ok ? soff + 2u * layer_bytes : 0u);
+  IT_LAP(4);
 }
 
 // ---- surface map (yakhip_volume.surface_map) --------------------------------------------------------
@@ -688,11 +853,15 @@ __device__ __forceinline__ void flush_bricks(const IntegrateParams& p, mask_t& b
 // in y -- so that a surface cutting through the layer sends fewer waves down the per-voxel path
 // (a wave takes it as soon as ONE lane is not settled by the group test).
 template <int VX>
-__device__ __forceinline__ bool lane_voxels(const IntegrateParams& p, uint32_t& elem, int& x0, int& y)
+__device__ __forceinline__ bool lane_voxels(const IntegrateParams& p, uint32_t block_x, uint32_t wave, uint32_t& elem, int& x0,
+                                            int& y)
 {
+  // (block_x, wave: the workgroup's place in the plane and the wave's in the workgroup -- blockIdx.x and
+  // threadIdx.x >> 6 in the kernel that walks the grid, a listed brick's in integrate_mixed_kernel)
+  const uint32_t lane = threadIdx.x & 63u;
   if (p.tile_shift >= 6)
   {
-    const uint32_t group = blockIdx.x * 256u + threadIdx.x;  // VX-voxel group inside one z layer
+    const uint32_t group = block_x * 256u + wave * 64u + lane;  // VX-voxel group inside one z layer
     if (group >= p.plane / VX)
       return false;
     elem = group * VX;
@@ -701,7 +870,6 @@ __device__ __forceinline__ bool lane_voxels(const IntegrateParams& p, uint32_t& 
     return true;
   }
   // the launcher only picks a tile that divides the layer: every lane owns voxels
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t lanes_x = 1u << p.tile_shift, rows_wave = 64u >> p.tile_shift;
   if (p.tile_side)
   {
@@ -709,14 +877,14 @@ __device__ __forceinline__ bool lane_voxels(const IntegrateParams& p, uint32_t& 
     // each row is one long contiguous run (memory sees what the layer-order footprint gives it) while every
     // wave's own patch stays compact (the brick test and the per-voxel path work wave by wave)
     const uint32_t blocks_per_row = (uint32_t)p.X / (4u * lanes_x * VX);
-    const uint32_t bx = blockIdx.x % blocks_per_row, by = blockIdx.x / blocks_per_row;
+    const uint32_t bx = block_x % blocks_per_row, by = block_x / blocks_per_row;
     x0 = (int)(((bx * 4u + wave) * lanes_x + (lane & (lanes_x - 1u))) * VX);
     y = (int)(by * rows_wave + (lane >> p.tile_shift));
   }
   else
   {
     const uint32_t blocks_per_row = (uint32_t)p.X / (lanes_x * VX);
-    const uint32_t bx = blockIdx.x % blocks_per_row, by = blockIdx.x / blocks_per_row;
+    const uint32_t bx = block_x % blocks_per_row, by = block_x / blocks_per_row;
     x0 = (int)((bx * lanes_x + (lane & (lanes_x - 1u))) * VX);
     y = (int)(by * 4u * rows_wave + wave * rows_wave + (lane >> p.tile_shift));
   }
@@ -741,59 +909,58 @@ __device__ __forceinline__ bool lane_voxels(const IntegrateParams& p, uint32_t& 
 // brick_eps bounds their distance per coordinate (host: (z1 + 32) * 2^-22 * P, P = largest |camera
 // coordinate| in the volume -- each of the <= z1 + 8 roundings is below 2^-24 * 2P) and every bound below is
 // widened by it; the pixel box by the matching projection error + 1/32 px for this routine's own roundings.
-enum BrickClass
-{
-  kBrickMixed = 0,
-  kBrickDead = 1,
-  kBrickFront = 2
-};
 
-// GROUP = 64: the calling wave settles its own brick, all lanes sharing the work.  GROUP = 8: every group of eight
-// lanes of the calling wave settles the brick of wave (lane / 8) of the workgroup (groups 4..7 repeat 0..3), so one
-// wave does the test for all four -- a quarter of the instructions, and on an orbit frame, where 82 % of the waves
-// are dead, the test is a sixth of all the kernel issues.  Returns the class of the lane's group.
-template <int VX, int GROUP>
-__device__ __forceinline__ int classify_brick(const IntegrateParams& p, int zs, int ze)
+// Voxel index ranges of wave `wave` of workgroup `block_x` in a layer (see lane_voxels); false: the wave owns nothing.
+template <int VX>
+__device__ __forceinline__ bool wave_footprint(const IntegrateParams& p, uint32_t block_x, uint32_t wave, int& xlo, int& xhi,
+                                               int& ylo, int& yhi)
 {
-  // voxel index ranges of the WAVE in question (see lane_voxels)
-  int xlo, xhi, ylo, yhi;
-  const uint32_t wave = GROUP == 64 ? threadIdx.x >> 6 : (threadIdx.x >> 3) & 3u;
   if (p.tile_shift >= 6)
   {
-    const uint32_t e0 = (blockIdx.x * 4u + wave) * (64u * VX);
+    const uint32_t e0 = (block_x * 4u + wave) * (64u * VX);
     uint32_t e1 = e0 + (64u * VX - 1u);
+    const bool owns = e0 < p.plane;
     if (e1 >= p.plane)
       e1 = p.plane - 1u;  // (a wave that starts beyond the layer owns nothing: its class is never used)
     ylo = (int)(e0 / (uint32_t)p.X);
     yhi = (int)(e1 / (uint32_t)p.X);
     xlo = ylo == yhi ? (int)(e0 - (uint32_t)ylo * (uint32_t)p.X) : 0;
     xhi = ylo == yhi ? (int)(e1 - (uint32_t)yhi * (uint32_t)p.X) : p.X - 1;
+    return owns;
+  }
+  const uint32_t lanes_x = 1u << p.tile_shift, rows_wave = 64u >> p.tile_shift;
+  if (p.tile_side)
+  {
+    const uint32_t blocks_per_row = (uint32_t)p.X / (4u * lanes_x * VX);
+    const uint32_t bx = block_x % blocks_per_row, by = block_x / blocks_per_row;
+    xlo = (int)((bx * 4u + wave) * lanes_x * VX);
+    ylo = (int)(by * rows_wave);
   }
   else
   {
-    const uint32_t lanes_x = 1u << p.tile_shift, rows_wave = 64u >> p.tile_shift;
-    if (p.tile_side)
-    {
-      const uint32_t blocks_per_row = (uint32_t)p.X / (4u * lanes_x * VX);
-      const uint32_t bx = blockIdx.x % blocks_per_row, by = blockIdx.x / blocks_per_row;
-      xlo = (int)((bx * 4u + wave) * lanes_x * VX);
-      ylo = (int)(by * rows_wave);
-    }
-    else
-    {
-      const uint32_t blocks_per_row = (uint32_t)p.X / (lanes_x * VX);
-      const uint32_t bx = blockIdx.x % blocks_per_row, by = blockIdx.x / blocks_per_row;
-      xlo = (int)(bx * lanes_x * VX);
-      ylo = (int)((by * 4u + wave) * rows_wave);
-    }
-    xhi = xlo + (int)(lanes_x * VX) - 1;
-    yhi = ylo + (int)rows_wave - 1;
+    const uint32_t blocks_per_row = (uint32_t)p.X / (lanes_x * VX);
+    const uint32_t bx = block_x % blocks_per_row, by = block_x / blocks_per_row;
+    xlo = (int)(bx * lanes_x * VX);
+    ylo = (int)((by * 4u + wave) * rows_wave);
   }
-  // corner (lane & 7) of the brick in camera space (every lane group of 8 computes the same 8 corners)
+  xhi = xlo + (int)(lanes_x * VX) - 1;
+  yhi = ylo + (int)rows_wave - 1;
+  return true;
+}
+
+// The test itself for the box of voxels [xlo, xhi] x [ylo, yhi] x [zlo, zhi] (inclusive), done by the GROUP lanes of the
+// calling lane's group (GROUP = 8 or 64; the box may differ from group to group).  FINE: the pixel box is looked up
+// in the 4-pixel cells when it covers no more than kFineMaxCells of them, which leaves far less of a brick undecided
+// beside a silhouette or the horizon (tools/sim_bricks.py: 16-pixel cells call 14.5 % of an orbit frame's wave bricks
+// mixed, the voxels themselves 7 %).  Returns the class of the lane's group.
+template <int GROUP, bool FINE>
+__device__ __forceinline__ int classify_box(const IntegrateParams& p, int xlo, int xhi, int ylo, int yhi, int zlo, int zhi)
+{
+  // corner (lane & 7) of the box in camera space (every lane group of 8 computes the same 8 corners)
   const uint32_t lane = threadIdx.x & 63u;
   const float vx = (float)((lane & 1u) ? xhi : xlo) * p.vsx;
   const float vy = (float)((lane & 2u) ? yhi : ylo) * p.vsy;
-  const float vz = (float)((lane & 4u) ? ze - 1 : zs) * p.vsz;
+  const float vz = (float)((lane & 4u) ? zhi : zlo) * p.vsz;
   const float cx = dot3(p.R[0], p.R[1], p.R[2], vx, vy, vz) + p.t[0];
   const float cy = dot3(p.R[3], p.R[4], p.R[5], vx, vy, vz) + p.t[1];
   const float cz = dot3(p.R[6], p.R[7], p.R[8], vx, vy, vz) + p.t[2];
@@ -801,8 +968,9 @@ __device__ __forceinline__ int classify_brick(const IntegrateParams& p, int zs, 
   float xmin = cx, xmax = cx, ymin = cy, ymax = cy, zmin = cz, zmax = cz;
   const float ax = __builtin_fabsf(cx) + e, ay = __builtin_fabsf(cy) + e, az = __builtin_fabsf(cz) + e;
   float d2max = __builtin_fmaf(ax, ax, __builtin_fmaf(ay, ay, az * az));
-  // projection of the corner (only meaningful, and only used, when the whole brick has z > brick_zmin)
-  const float iz = 1.f / cz;
+  // projection of the corner (only meaningful, and only used, when the whole brick has z > brick_zmin; the hardware
+  // reciprocal is good to 1 ulp, 1e-4 px in a 1000 px image: inside the 1/32 px the box is widened by for such things)
+  const float iz = __builtin_amdgcn_rcpf(cz);
   float umin = __builtin_fmaf(p.fx, cx * iz, p.cx), vmin = __builtin_fmaf(p.fy, cy * iz, p.cy);
   float umax = umin, vmax = vmin;
 #pragma unroll
@@ -828,7 +996,7 @@ __device__ __forceinline__ int classify_brick(const IntegrateParams& p, int zs, 
   {
     const float xabs = __builtin_fmaxf(__builtin_fabsf(xmin), __builtin_fabsf(xmax));
     const float yabs = __builtin_fmaxf(__builtin_fabsf(ymin), __builtin_fabsf(ymax));
-    const float rz = 1.f / (zmin - e);
+    const float rz = __builtin_amdgcn_rcpf(zmin - e);  // (the factor 1.01 below covers its ulp)
     const float du = __builtin_fmaf(p.fx * e * (1.f + xabs * rz), rz * 1.01f, 1.f / 32.f);
     const float dv = __builtin_fmaf(p.fy * e * (1.f + yabs * rz), rz * 1.01f, 1.f / 32.f);
     umin -= du, umax += du, vmin -= dv, vmax += dv;
@@ -840,18 +1008,47 @@ __device__ __forceinline__ int classify_brick(const IntegrateParams& p, int zs, 
       // cells the box touches, clipped to the image
       const int px0 = (int)__builtin_fmaxf(__builtin_floorf(umin), 0.f), px1 = (int)__builtin_fminf(__builtin_floorf(umax), fc - 1.f);
       const int py0 = (int)__builtin_fmaxf(__builtin_floorf(vmin), 0.f), py1 = (int)__builtin_fminf(__builtin_floorf(vmax), fr - 1.f);
-      const int cx0 = px0 / kBrickCell, cy0 = py0 / kBrickCell;
-      const int ncx = px1 / kBrickCell - cx0 + 1, ncy = py1 / kBrickCell - cy0 + 1;
+      int cx0 = px0 / kBrickCell, cy0 = py0 / kBrickCell;
+      int ncx = px1 / kBrickCell - cx0 + 1, ncy = py1 / kBrickCell - cy0 + 1;
+      int pitch = p.ccw;
+      const float *lo_plane = p.cellmin, *hi_plane = p.cellmax;
+      if constexpr (FINE)
+      {
+        const int fx0 = px0 >> kFineShift, fy0 = py0 >> kFineShift;
+        const int nfx = (px1 >> kFineShift) - fx0 + 1, nfy = (py1 >> kFineShift) - fy0 + 1;
+        if (nfx * nfy <= kFineMaxCells)
+          cx0 = fx0, cy0 = fy0, ncx = nfx, ncy = nfy, pitch = p.fcw, lo_plane = p.finemin, hi_plane = p.finemax;
+      }
       const int n = ncx * ncy;
       if (n <= 256)
       {
         float amin = __builtin_inff(), bmax = -__builtin_inff();
-        for (int i = (int)(lane & (GROUP - 1)); i < n; i += GROUP)
+        // (four cells per trip, their loads issued together: the trips of a piece are round trips to L2 one after
+        //  the other otherwise, the larger part of the test's time)
+        const float rncx = __builtin_amdgcn_rcpf((float)ncx);
+        for (int i0 = (int)(lane & (GROUP - 1)); i0 < n; i0 += 4 * GROUP)
         {
-          const int yy = i / ncx, xx = i - yy * ncx;
-          const int idx = (cy0 + yy) * p.ccw + cx0 + xx;
-          amin = __builtin_fminf(amin, p.cellmin[idx]);
-          bmax = __builtin_fmaxf(bmax, p.cellmax[idx]);
+          float lo[4], hi[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+          {
+            const int i = i0 + u * GROUP;
+            const bool on = i < n;
+            // i / ncx for 0 <= i < 65536, ncx <= 256: the rounded-down float quotient is exact or one too large
+            int yy = (int)((float)i * rncx);
+            yy -= yy * ncx > i ? 1 : 0;
+            yy += (yy + 1) * ncx <= i ? 1 : 0;
+            const int xx = i - yy * ncx;
+            const int idx = on ? (cy0 + yy) * pitch + cx0 + xx : cy0 * pitch + cx0;
+            lo[u] = lo_plane[idx];
+            hi[u] = hi_plane[idx];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+          {
+            amin = __builtin_fminf(amin, lo[u]);  // (a lane past the end re-reads the box's first cell: harmless)
+            bmax = __builtin_fmaxf(bmax, hi[u]);
+          }
         }
 #pragma unroll
         for (int off = GROUP / 2; off > 0; off >>= 1)
@@ -871,10 +1068,47 @@ __device__ __forceinline__ int classify_brick(const IntegrateParams& p, int zs, 
       }
     }
   }
+  return cls;
+}
+
+// GROUP = 64: the calling wave settles its own brick, all lanes sharing the work.  GROUP = 8: every group of eight
+// lanes of the calling wave settles the brick of wave (lane / 8) of the workgroup (groups 4..7 repeat 0..3), so one
+// wave does the test for all four -- a quarter of the instructions, and on an orbit frame, where 82 % of the waves
+// are dead, the test is a sixth of all the kernel issues.  Returns the class of the lane's group.
+template <int VX, int GROUP>
+__device__ __forceinline__ int classify_brick(const IntegrateParams& p, uint32_t block_x, int zs, int ze)
+{
+  int xlo, xhi, ylo, yhi;
+  const uint32_t wave = GROUP == 64 ? threadIdx.x >> 6 : (threadIdx.x >> 3) & 3u;
+  wave_footprint<VX>(p, block_x, wave, xlo, xhi, ylo, yhi);
+  const int cls = classify_box<GROUP, false>(p, xlo, xhi, ylo, yhi, zs, ze - 1);
   if constexpr (GROUP == 64)
     return __builtin_amdgcn_readfirstlane(cls);
   else
     return cls;
+}
+
+// A mixed brick once more, in up to eight pieces along z of 1 << shift layers each -- piece g by lanes 8g .. 8g + 7,
+// against the fine cells.  A piece's pixel box is a fraction of the brick's and the planes it is looked up in are
+// sixteen times finer, so most of what the first test left undecided next to a silhouette, the horizon or the image
+// border is settled here: on an orbit frame 40 % of a mixed brick's layers (tools/sim_bricks.py).  Returns the lanes of
+// the dead and of the front pieces as wave masks (all eight lanes of a group alike; groups past the brick's last
+// layer count as dead).
+template <int VX>
+__device__ __forceinline__ void classify_pieces(const IntegrateParams& p, uint32_t block_x, uint32_t wave, int zs, int ze,
+                                                int shift, mask_t& dead, mask_t& front)
+{
+  int xlo, xhi, ylo, yhi;
+  wave_footprint<VX>(p, block_x, wave, xlo, xhi, ylo, yhi);
+  const int g = (int)((threadIdx.x & 63u) >> 3);
+  const int zlo = zs + (g << shift);
+  int zhi = zlo + (1 << shift) - 1;
+  if (zhi > ze - 1)
+    zhi = ze - 1;
+  const bool empty = zlo >= ze;
+  const int cls = classify_box<8, true>(p, xlo, xhi, ylo, yhi, empty ? zs : zlo, empty ? zs : zhi);
+  dead = ballot(empty || cls == kBrickDead);
+  front = ballot(!empty && cls == kBrickFront);
 }
 
 // A "front" brick: every voxel of the chunk takes the measurement 1.0.  Plain streaming: two layers in flight.
@@ -908,102 +1142,62 @@ __device__ __forceinline__ void walk_front(const IntegrateParams& p, rsrc_t rs, 
   }
 }
 
-// VX voxels per lane along x.  The z loop is software-pipelined two layers deep with two register
-// sets (A, B): while layer z is being settled and written, layer z+1 is already tested/projected
-// (its threshold gathers in flight), and the voxels of layers z+1 / z+2 are being fetched.
-#ifdef YAK_INTEGRATE_TIMING
-// diagnostic build only (make EXTRA=-DYAK_INTEGRATE_TIMING; tools/bench_orbit_waves.py): per wave of the last launch
-// {class + 1, shader-clock cycles in all, cycles to the end of the brick test, replay cycles,
-//  layers walked | duration in 10 ns ticks << 16, HW_ID << 40 | start on the device-wide 100 MHz clock}
-constexpr int kItSlots = 1 << 17;
-__device__ unsigned long long g_it_time[kItSlots][6];
-#define IT_CLOCK(var) var = __builtin_readcyclecounter()
-#define IT_ROW(cls_, t_cls_, t_replay_, layers_)                                                                          \
-  do                                                                                                                     \
-  {                                                                                                                      \
-    if ((threadIdx.x & 63u) == 0)                                                                                        \
-    {                                                                                                                    \
-      unsigned hw;                                                                                                       \
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                                   \
-      unsigned long long* row =                                                                                          \
-          g_it_time[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) & (kItSlots - 1)];          \
-      const unsigned long long it_now = __builtin_readcyclecounter();                                                    \
-      row[0] = (unsigned long long)(cls_) + 1, row[1] = it_now - it_t0, row[2] = (t_cls_) - it_t0, row[3] = (t_replay_); \
-      row[4] = (unsigned long long)(layers_) | ((__builtin_amdgcn_s_memrealtime() - it_r0) << 16);                       \
-      row[5] = ((unsigned long long)hw << 40) | (it_r0 & 0xffffffffffull);                                               \
-    }                                                                                                                    \
-  } while (0)
-#else
-#define IT_CLOCK(var)
-#define IT_ROW(cls_, t_cls_, t_replay_, layers_)
-#endif
-template <int VX, bool NT>
-__global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams p, const ChunkTable chunks)
+// The same with DEPTH layers in flight, for launches where front bricks are few and far between (a launch with a list:
+// a surface-rich frame): a wave that streams alone is bound by the round trip to memory, one per two layers above --
+// 24 layers took a front wave 15 to 37 us, the longest jobs of the first kernel.
+template <int VX, bool NT, int DEPTH>
+__device__ __forceinline__ void walk_front_deep(const IntegrateParams& p, rsrc_t rs, uint32_t voff, uint32_t layer_bytes,
+                                                int layers, mask_t active, uint32_t max_w_hi)
 {
-#ifdef YAK_INTEGRATE_TIMING
-  unsigned long long it_t0, it_t1 = 0, it_t2 = 0, it_t3 = 0;
-  const unsigned long long it_r0 = __builtin_amdgcn_s_memrealtime();
-  IT_CLOCK(it_t0);
-#endif
   typedef typename Vec<VX>::type vec_t;
-  extern __shared__ __attribute__((aligned(16))) float coarse_lds[];
-
-  // The chunk this workgroup walks comes from the launcher's table (chunk_table below): layers [zs, ze), in the
-  // order the launcher wants them dispatched.
-  const int zs = p.z0 + __builtin_amdgcn_readfirstlane((int)chunks.first[blockIdx.y]);
-  const int ze = zs + __builtin_amdgcn_readfirstlane((int)chunks.layers[blockIdx.y]);
-
-  // brick test: the class of every wave's brick, settled by the first wave for all four (eight lanes per brick) and
-  // handed over through LDS
-  __shared__ int wave_class[4];
-  int cls = kBrickMixed;
-  bool fill = VX == 4 && p.grp_enable;
-  if (p.brick_enable)
+  mask_t hit[VX], unit[VX];
+  float tsdf[VX];
+#pragma unroll
+  for (int v = 0; v < VX; ++v)
   {
-    if (threadIdx.x < 64u)
+    hit[v] = unit[v] = active;
+    tsdf[v] = 1.f;
+  }
+  vec_t b[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+    b[d] = buf_load<VX, NT>(rs, d < layers ? voff : kNoAccess, d < layers ? (uint32_t)d * layer_bytes : 0u);
+  uint32_t soff = 0;
+  for (int i = 0; i < layers; i += DEPTH, soff += (uint32_t)DEPTH * layer_bytes)
+  {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
     {
-      const int c = classify_brick<VX, 8>(p, zs, ze);
-      if (threadIdx.x < 32u && (threadIdx.x & 7u) == 0)
-        wave_class[threadIdx.x >> 3] = c;
+      const bool on = i + d < layers, ahead = i + d + DEPTH < layers;
+      vec_t o = b[d];
+      fuse_run<VX>(b[d], o, hit, unit, tsdf, p.max_weight, max_w_hi);
+      buf_store<VX, NT>(o, rs, on ? voff : kNoAccess, on ? soff + (uint32_t)d * layer_bytes : 0u);
+      b[d] = buf_load<VX, NT>(rs, ahead ? voff : kNoAccess, ahead ? soff + (uint32_t)(d + DEPTH) * layer_bytes : 0u);
     }
-    __syncthreads();
-    cls = __builtin_amdgcn_readfirstlane(wave_class[threadIdx.x >> 6]);
-    // The coarse threshold image (a few KiB, read once per workgroup into LDS) is only needed by mixed bricks.
-    fill = fill && (wave_class[0] == kBrickMixed || wave_class[1] == kBrickMixed || wave_class[2] == kBrickMixed ||
-                    wave_class[3] == kBrickMixed);
   }
-  if (p.brick_stats && (threadIdx.x & 63u) == 0)  // measurement aid, off by default
-    atomicAdd(&p.brick_stats[cls], 1u);
-  if (fill)
-  {
-    const int n = p.cw * p.ch;
-    for (int i = (int)threadIdx.x; i < n; i += 256)
-      coarse_lds[i] = p.coarse[i];
-    __syncthreads();
-  }
-  IT_CLOCK(it_t1);
-  if (cls == kBrickDead)
-  {
-    IT_ROW(cls, it_t1, 0, 0);
-    return;
-  }
+}
 
+
+// The per-voxel walk of the layers [ws, we) of wave `wave` of workgroup `block_x`: VX voxels per lane along x.  The z
+// loop is software-pipelined two layers deep with two register sets (A, B): while layer z is being settled and
+// written, layer z+1 is already tested/projected (its threshold gathers in flight), and the voxels of layers
+// z+1 / z+2 are being fetched.
+// piece_dead / piece_front (classify_pieces; 0 / 0 = nothing known): the class of the pieces of 1 << piece_shift layers
+// counted from layer zs, eight mask bits per piece.
+template <int VX, bool NT, bool PIECES>
+__device__ __forceinline__ void walk_mixed(const IntegrateParams& p, const float* coarse_lds, uint32_t block_x, uint32_t wave,
+                                           int zs, int ws, int we, mask_t piece_dead, mask_t piece_front, int piece_shift
+#ifdef YAK_INTEGRATE_TIMING
+                                           , unsigned long long& it_replay, size_t it_slot
+#endif
+)
+{
+  typedef typename Vec<VX>::type vec_t;
   uint32_t elem;  // x + y*X of the lane's first voxel; X % VX == 0 so no row straddle
   int x0, y;
-  if (!lane_voxels<VX>(p, elem, x0, y))
+  if (!lane_voxels<VX>(p, block_x, wave, elem, x0, y))
     return;
   const mask_t active = ballot(true);
-
-  if (cls == kBrickFront)
-  {
-    const uint32_t lb = p.plane * 4u;
-    const rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(p.vol + (size_t)(zs - p.z0) * p.plane, 0,
-                                                         (uint32_t)(ze - zs) * lb, 0x00020000);
-    walk_front<VX, NT>(p, rsf, elem * 4u, lb, ze - zs, active, ((uint32_t)p.max_weight << 16) | 0xffffu);
-    IT_ROW(cls, it_t1, 0, ze - zs);
-    return;
-  }
-  const int ws = zs, we = ze;  // the layers walked voxel by voxel
 
   // :69
   const float zsx = p.R[2] * p.vsz, zsy = p.R[5] * p.vsz, zsz = p.R[8] * p.vsz;
@@ -1025,10 +1219,24 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
       A.z[k][h] = dot3(p.R[6], p.R[7], p.R[8], vxx, vxy, 0.f) + p.t[2];
     }
 
-  // Replay the additions the reference performed on layers [0, zs) (tsdf_volume.cu:76), ws of them here -- from layer 0, or
+  // Replay the additions the reference performed on layers [0, ws) (tsdf_volume.cu:76), ws of them here -- from layer 0, or
   // for a slab deep inside a tall volume from the column positions at z0 that checkpoint_kernel left.
   int replay = ws;
-  if (p.ckpt)
+  if (PIECES && p.cptab)
+  {
+    // ... or, in a launch with a list, from the checkpoint below ws that the first kernel wrote
+    if constexpr (VX == 4)
+    {
+      const int k = (ws - p.z0) / p.cp_stride;
+      const float* at = p.cptab + (size_t)k * 3u * p.plane + elem;
+      const f32x4 cx = *(const f32x4*)at, cy = *(const f32x4*)(at + p.plane), cz = *(const f32x4*)(at + 2u * p.plane);
+      A.x[0] = f32x2{ cx[0], cx[3] }, A.x[1] = f32x2{ cx[1], cx[2] };
+      A.y[0] = f32x2{ cy[0], cy[3] }, A.y[1] = f32x2{ cy[1], cy[2] };
+      A.z[0] = f32x2{ cz[0], cz[3] }, A.z[1] = f32x2{ cz[1], cz[2] };
+      replay = ws - p.z0 - k * p.cp_stride;
+    }
+  }
+  else if (p.ckpt)
   {
 #pragma unroll
     for (int k = 0; k < Pos<VX>::NP; ++k)
@@ -1043,10 +1251,16 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
       }
     replay = ws - p.z0;
   }
-  IT_CLOCK(it_t2);
+#ifdef YAK_INTEGRATE_TIMING
+  unsigned long long it_a, it_b;
+  IT_CLOCK(it_a);
+#endif
   for (int i = 0; i < replay; ++i)
     advance<VX>(A, A, sx, sy, sz);
-  IT_CLOCK(it_t3);
+#ifdef YAK_INTEGRATE_TIMING
+  IT_CLOCK(it_b);
+  it_replay = it_b - it_a;
+#endif
 
   const f32x2 fx2 = { p.fx, p.fx }, fy2 = { p.fy, p.fy }, cx2 = { p.cx, p.cx }, cy2 = { p.cy, p.cy };
   const uint32_t max_w_hi = ((uint32_t)p.max_weight << 16) | 0xffffu;
@@ -1056,6 +1270,17 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
   const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.vol + (size_t)(ws - p.z0) * p.plane, 0,
                                                       (uint32_t)(we - ws) * layer_bytes, 0x00020000);
   const uint32_t voff = elem * 4u;
+  // what classify_pieces said of layer z (wave-uniform); layers past the walk's end count as dead: stage 1 runs a
+  // layer ahead, and a dead layer costs it nothing
+  auto layer_class = [&](int z) -> int {
+    if constexpr (!PIECES)
+      return kBrickMixed;  // (stage 1 is then not guarded at the walk's end: a projection past `we` reads valid
+                           //  threshold texels and is discarded)
+    if (z >= we)
+      return kBrickDead;
+    const int bit = ((z - zs) >> piece_shift) << 3;
+    return ((piece_dead >> bit) & 1ull) ? kBrickDead : (((piece_front >> bit) & 1ull) ? kBrickFront : kBrickMixed);
+  };
 
   // Prologue, shaped like one steady-state half trip so that the compiler's s_waitcnt counting sees
   // the same queue at loop entry as on the back edge: [voxel fetch] [stage 1] [store] [voxel fetch].
@@ -1065,7 +1290,7 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
   mask_t validA = ~0ull, validB = ws + 1 < we ? ~0ull : 0ull;
   vec_t bufA = buf_load<VX, NT>(rs, voff, 0u);
   __builtin_amdgcn_sched_barrier(0);
-  stage1<VX>(p, A, PA, coarse_lds, active, fx2, fy2, cx2, cy2);
+  stage1<VX>(p, A, PA, coarse_lds, active, fx2, fy2, cx2, cy2, layer_class(ws));
   __builtin_amdgcn_sched_barrier(0);
   buf_store<VX, NT>(bufA, rs, kNoAccess, 0u);
   vec_t bufB = buf_load<VX, NT>(rs, validB ? voff : kNoAccess, validB ? layer_bytes : 0u);
@@ -1073,25 +1298,396 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
   uint32_t soff = 0;
   mask_t band = 0;  // lanes that folded a negative measurement into a voxel since the last flush (surface map)
   mask_t marked = 0;  // ... at any time during this walk
+#ifdef YAK_INTEGRATE_TIMING
+  ItPhase itp = {};
+#endif
   for (int z = ws; z < we; z += 2, soff += 2u * layer_bytes)
   {
-    // layer z lives in set A, layer z+1 in set B.  Stage 1 runs one layer ahead and is not guarded at
-    // the walk's end: a projection past we reads valid threshold texels and is discarded.
-    advance<VX>(A, B, sx, sy, sz);
-    stage1<VX>(p, B, PB, coarse_lds, active, fx2, fy2, cx2, cy2);
-    update<VX, NT>(p, A, PA, bufA, validA, rs, voff, soff, layer_bytes, true, z + 2 < we, max_w_hi, band);
-    advance<VX>(B, A, sx, sy, sz);
-    stage1<VX>(p, A, PA, coarse_lds, active, fx2, fy2, cx2, cy2);
+    // layer z lives in set A, layer z+1 in set B.  Stage 1 runs one layer ahead.
+    {
+      IT_LAP_START;
+      advance<VX>(A, B, sx, sy, sz);
+      stage1<VX>(p, B, PB, coarse_lds, active, fx2, fy2, cx2, cy2, layer_class(z + 1));
+      IT_LAP(0);
+    }
+    update<VX, NT>(p, A, PA, bufA, validA, rs, voff, soff, layer_bytes, true, z + 2 < we, max_w_hi, band IT_PHASE_ARG);
+    {
+      IT_LAP_START;
+      advance<VX>(B, A, sx, sy, sz);
+      stage1<VX>(p, A, PA, coarse_lds, active, fx2, fy2, cx2, cy2, layer_class(z + 2));
+      IT_LAP(0);
+    }
     update<VX, NT>(p, B, PB, bufB, validB, rs, voff, soff + layer_bytes, layer_bytes, z + 1 < we, z + 3 < we,
-                   max_w_hi, band);
+                   max_w_hi, band IT_PHASE_ARG);
     if (p.bricks)
       flush_bricks(p, band, marked, x0, y, z, 2, we);
   }
   if (p.bricks)
     mark_cells(p, marked, x0, y, ws - p.z0, we - p.z0);
-  IT_ROW(cls, it_t1, it_t3 - it_t2, we - ws);
+#ifdef YAK_INTEGRATE_TIMING
+  if ((threadIdx.x & 63u) == 0)
+    for (int i = 0; i < 8; ++i)
+      g_it_phase[it_slot & (kItSlots - 1)][i] = itp.t[i];
+#endif
+}
+
+// Column checkpoints of a launch with a list (IntegrateParams::cptab): the camera-space positions of columns
+// col .. col + 3 at the layers z0, z0 + cp_stride, ... exactly as the walk would have them there.
+__device__ __forceinline__ void checkpoint_table(const IntegrateParams& p, uint32_t col)
+{
+  if (col >= p.plane)
+    return;
+  const int y = (int)(col / (uint32_t)p.X), x0 = (int)(col - (uint32_t)y * (uint32_t)p.X);
+  const float zsx = p.R[2] * p.vsz, zsy = p.R[5] * p.vsz, zsz = p.R[8] * p.vsz;  // :69
+  const f32x2 sx = { zsx, zsx }, sy = { zsy, zsy }, sz = { zsz, zsz };
+  Pos<4> A;
+  const float vxy = (float)y * p.vsy;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+    {
+      const int v = Pos<4>::voxel(k, h);
+      if (p.ckpt)
+      {
+        A.x[k][h] = p.ckpt[col + v], A.y[k][h] = p.ckpt[p.plane + col + v], A.z[k][h] = p.ckpt[2u * p.plane + col + v];
+      }
+      else
+      {
+        const float vxx = (float)(x0 + v) * p.vsx;  // :71-72
+        A.x[k][h] = dot3(p.R[0], p.R[1], p.R[2], vxx, vxy, 0.f) + p.t[0];
+        A.y[k][h] = dot3(p.R[3], p.R[4], p.R[5], vxx, vxy, 0.f) + p.t[1];
+        A.z[k][h] = dot3(p.R[6], p.R[7], p.R[8], vxx, vxy, 0.f) + p.t[2];
+      }
+    }
+  if (!p.ckpt)
+    for (int i = 0; i < p.z0; ++i)  // (a slab that starts a few layers up and has no closed-form checkpoint)
+      advance<4>(A, A, sx, sy, sz);
+  float* at = p.cptab + col;
+  for (int k = 0; k < p.cp_count; ++k, at += 3u * p.plane)
+  {
+    *(f32x4*)at = f32x4{ A.x[0][0], A.x[1][0], A.x[1][1], A.x[0][1] };
+    *(f32x4*)(at + p.plane) = f32x4{ A.y[0][0], A.y[1][0], A.y[1][1], A.y[0][1] };
+    *(f32x4*)(at + 2u * p.plane) = f32x4{ A.z[0][0], A.z[1][0], A.z[1][1], A.z[0][1] };
+    if (k + 1 < p.cp_count)
+      for (int i = 0; i < p.cp_stride; ++i)
+        advance<4>(A, A, sx, sy, sz);
+  }
+}
+
+// The launch's grid walks (plane tiles) x (z chunks).  Every workgroup settles its four wave bricks first: a dead
+// brick ends there, a front brick is streamed, a mixed one is walked voxel by voxel.  This is the whole launch for
+// frames that are mostly free space (the wall scene: the roofline case) and for small volumes; a surface-rich frame
+// of a large volume goes through the two kernels below instead.
+template <int VX, bool NT>
+__global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams p, const ChunkTable chunks)
+{
+  IT_BEGIN;
+  extern __shared__ __attribute__((aligned(16))) float coarse_lds[];
+
+  // The chunk this workgroup walks comes from the launcher's table (chunk_table below): layers [zs, ze), in the
+  // order the launcher wants them dispatched.
+  const int zs = p.z0 + __builtin_amdgcn_readfirstlane((int)chunks.first[blockIdx.y]);
+  const int ze = zs + __builtin_amdgcn_readfirstlane((int)chunks.layers[blockIdx.y]);
+  const uint32_t wave = threadIdx.x >> 6;
+#ifdef YAK_INTEGRATE_TIMING
+  const size_t it_slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+#endif
+
+  // brick test: the class of every wave's brick, settled by the first wave for all four (eight lanes per brick) and
+  // handed over through LDS
+  __shared__ int wave_class[4];
+  int cls = kBrickMixed;
+  bool fill = VX == 4 && p.grp_enable;
+  if (p.brick_enable)
+  {
+    if (threadIdx.x < 64u)
+    {
+      const int c = classify_brick<VX, 8>(p, blockIdx.x, zs, ze);
+      if (threadIdx.x < 32u && (threadIdx.x & 7u) == 0)
+      {
+        wave_class[threadIdx.x >> 3] = c;
+        if (p.classes)  // what this launch found, for the launcher's choice of kernels for a later frame (class bytes
+        {               // as classify_kernel leaves them)
+          int xlo, xhi, ylo, yhi;
+          const bool owns = wave_footprint<VX>(p, blockIdx.x, threadIdx.x >> 3, xlo, xhi, ylo, yhi);
+          const int pl = part_layers(ze - zs);
+          const uint32_t parts = (uint32_t)((ze - zs + pl - 1) / pl);
+          p.classes[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 3)] =
+              (uint8_t)(c == kBrickDead || !owns ? 0u : (c == kBrickFront ? parts | 0x80u : parts));
+        }
+      }
+    }
+    __syncthreads();
+    cls = __builtin_amdgcn_readfirstlane(wave_class[wave]);
+    // The coarse threshold image (a few KiB, read once per workgroup into LDS) is only needed by mixed bricks.
+    fill = fill && (wave_class[0] == kBrickMixed || wave_class[1] == kBrickMixed || wave_class[2] == kBrickMixed ||
+                    wave_class[3] == kBrickMixed);
+  }
+  if (p.brick_stats && (threadIdx.x & 63u) == 0)  // measurement aid, off by default
+    atomicAdd(&p.brick_stats[cls], 1u);
+  if (fill)
+  {
+    const int n = p.cw * p.ch;
+    for (int i = (int)threadIdx.x; i < n; i += 256)
+      coarse_lds[i] = p.coarse[i];
+    __syncthreads();
+  }
+  IT_CLOCK(it_t1);
+  if (cls == kBrickDead)
+  {
+    IT_ROW(it_slot, cls, it_t1, 0, 0);
+    return;
+  }
+  if (cls == kBrickFront)
+  {
+    uint32_t elem;
+    int x0, y;
+    if (!lane_voxels<VX>(p, blockIdx.x, wave, elem, x0, y))
+      return;
+    const uint32_t lb = p.plane * 4u;
+    const rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(p.vol + (size_t)(zs - p.z0) * p.plane, 0,
+                                                         (uint32_t)(ze - zs) * lb, 0x00020000);
+    walk_front<VX, NT>(p, rsf, elem * 4u, lb, ze - zs, ballot(true), ((uint32_t)p.max_weight << 16) | 0xffffu);
+    IT_ROW(it_slot, cls, it_t1, 0, ze - zs);
+    return;
+  }
+#ifdef YAK_INTEGRATE_TIMING
+  walk_mixed<VX, NT, false>(p, coarse_lds, blockIdx.x, wave, zs, zs, ze, 0, 0, 31, it_t3, it_slot);
+#else
+  walk_mixed<VX, NT, false>(p, coarse_lds, blockIdx.x, wave, zs, zs, ze, 0, 0, 31);  // (nothing known of its pieces)
+#endif
+  IT_ROW(it_slot, cls, it_t1, it_t3, ze - zs);
+}
+
+// ---- a launch in two kernels: surface-rich frames of large volumes --------------------------------
+// Mixed bricks are few (4 000 of an orbit frame's 30 000 wave bricks), cost ten to forty times a front brick, and sit
+// where the surfaces are.  Walked in place by the grid above, all of them are resident within the first eighth of
+// the launch -- ten to a SIMD here, none there, every one a chain of 24 layers behind a replay of up to 500 steps --
+// and the launch lasts as long as its most loaded SIMD (per-wave clocks of an orbit view: SIMDs end anywhere between
+// 68 and 125 us of 125).  So the work is cut finer and dealt out evenly:
+//   classify_kernel        the brick test for every wave brick of the grid above, eight lanes per brick, the classes
+//                          left in memory (a byte per brick); and, by extra workgroups, the camera-space positions of
+//                          every column every cp_stride layers, so that nobody replays from layer 0 again
+//   integrate_list_kernel  a fixed number of workgroups; each reads all the classes, numbers the live bricks' parts
+//                          (kPartLayers layers each) the same way as every other workgroup does, keeps every G-th one
+//                          -- no list in memory, no atomics, every workgroup the same count -- and its four waves take
+//                          them from a counter in LDS as they come free.
+// The voxels come out word for word as from the grid above: the same walk over the same layers from the same positions.
+constexpr uint32_t kClassUnits = 7u, kClassFront = 0x80u;  // a class byte: parts to do (0 = dead) | front
+
+template <int VX>
+__global__ __launch_bounds__(256) void classify_kernel(const IntegrateParams p, const ChunkTable chunks, uint32_t rows_x)
+{
+  static_assert(VX == 4, "the two-kernel launch is for the 16-byte layout");
+  // the first grid_x workgroups write the column checkpoints (dispatched first: the launch's longest jobs): lane = four
+  // columns, positions as the walk forms and advances them (tsdf_volume.cu:69-76)
+  if (blockIdx.x < p.grid_x)
+  {
+    checkpoint_table(p, (blockIdx.x * 256u + threadIdx.x) * 4u);
+    return;
+  }
+  // then rows_x workgroups per chunk, 32 wave bricks each
+  const uint32_t id = blockIdx.x - p.grid_x;
+  const uint32_t cj = id / rows_x, in_chunk = (id - cj * rows_x) * 32u + (threadIdx.x >> 3);
+  const int zs = p.z0 + __builtin_amdgcn_readfirstlane((int)chunks.first[cj]);
+  const int ze = zs + __builtin_amdgcn_readfirstlane((int)chunks.layers[cj]);
+  if (in_chunk >= p.grid_x * 4u)
+    return;
+  int xlo, xhi, ylo, yhi;
+  const bool owns = wave_footprint<VX>(p, in_chunk >> 2, in_chunk & 3u, xlo, xhi, ylo, yhi);
+  int cls = classify_box<8, false>(p, xlo, xhi, ylo, yhi, zs, ze - 1);
+  if (!owns)
+    cls = kBrickDead;
+  if ((threadIdx.x & 7u) == 0)
+  {
+    const int pl = part_layers(ze - zs);
+    const uint32_t parts = (uint32_t)((ze - zs + pl - 1) / pl);  // <= 4
+    p.classes[(size_t)cj * p.grid_x * 4u + in_chunk] =
+        (uint8_t)(cls == kBrickDead ? 0u : (cls == kBrickFront ? parts | kClassFront : parts));
+    if (p.brick_stats)  // measurement aid, off by default
+      atomicAdd(&p.brick_stats[cls], 1u);
+  }
+}
+
+template <int VX, bool NT>
+__global__ __launch_bounds__(256, 5) void integrate_list_kernel(const IntegrateParams p_arg, const ChunkTable chunks, int refine,
+                                                                uint32_t list_cap)
+{
+  extern __shared__ __attribute__((aligned(16))) float coarse_lds[];
+  // The parameters are read through a pointer the compiler cannot see through, renewed for every part: otherwise
+  // it loads all of them once, in front of the loop over the parts, and keeps them in scalar registers through the
+  // walk, which then spills a hundred of them (measured: 128 spilled SGPRs and 37 VGPRs to scratch; 24 / 0 so).
+  // p_arg is the kernel's first argument: it starts the kernarg segment.
+  typedef const __attribute__((address_space(4))) IntegrateParams* params_ptr;
+  params_ptr pq = (params_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(pq));
+#define p (*(const IntegrateParams*)pq)
+  const int coarse_n = VX == 4 && p.grp_enable ? p.cw * p.ch : 0;
+  uint32_t* my_parts = (uint32_t*)(coarse_lds + coarse_n);  // this workgroup's share, list_cap entries
+  __shared__ uint32_t wave_sum[4], share_n, share_next;
+  for (int i = (int)threadIdx.x; i < coarse_n; i += 256)
+    coarse_lds[i] = p.coarse[i];
+
+  // Number the parts of the live bricks, the same way in every workgroup: thread t counts the bricks 4 t .. 4 t + 3 of
+  // every group of 1024 (one word of four class bytes per group), the threads' counts are summed up in thread order,
+  // and a part whose number is g modulo G belongs to workgroup g.
+  const uint32_t G = gridDim.x, g = blockIdx.x;
+  const uint32_t groups = (p.n_bricks + 1023u) >> 10;
+  const uint32_t* words = (const uint32_t*)p.classes;  // (padded with zeros to whole groups)
+  uint32_t mine = 0;
+  for (uint32_t i = 0; i < groups; ++i)
+  {
+    const uint32_t w = words[i * 256u + threadIdx.x] & 0x07070707u;
+    mine += (w * 0x01010101u) >> 24;  // the four counts added up
+  }
+  uint32_t incl = mine;  // inclusive scan over the wave, then over the four waves
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1)
+  {
+    const uint32_t up = __shfl_up(incl, off);
+    if ((int)(threadIdx.x & 63u) >= off)
+      incl += up;
+  }
+  if ((threadIdx.x & 63u) == 63u)
+    wave_sum[threadIdx.x >> 6] = incl;
+  if (threadIdx.x == 0)
+    share_next = 0;
+  __syncthreads();
+  uint32_t number = incl - mine;  // of this thread's first part
+  for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w)
+    number += wave_sum[w];
+  const uint32_t total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+  if (total == 0)  // (every wave of the grid finds the same: nothing to do)
+    return;
+  if (mine != 0)
+  {
+    // this thread's parts carry the numbers [number, number + mine): those that are g modulo G are this workgroup's
+    // (mine < G for every volume that is not huge: at most one)
+    const uint32_t r = number % G;
+    uint32_t target = number + (g >= r ? g - r : g + G - r);
+    uint32_t i = 0, seen = number;  // parts of the words before word i
+    while (target < number + mine)
+    {
+      uint32_t w = 0, cnt = 0;
+      for (; i < groups; ++i)
+      {
+        w = words[i * 256u + threadIdx.x];
+        cnt = ((w & 0x07070707u) * 0x01010101u) >> 24;
+        if (seen + cnt > target)
+          break;
+        seen += cnt;
+      }
+      uint32_t at = seen;  // the part is in word i: which brick, which part of it
+      for (uint32_t k = 0; k < 4u; ++k)
+      {
+        const uint32_t c = (w >> (8u * k)) & 0xffu, u = c & kClassUnits;
+        if (at + u > target)
+        {
+          const uint32_t slot = target / G;
+          if (slot < list_cap)
+            my_parts[slot] = ((i * 256u + threadIdx.x) * 4u + k) | ((target - at) << 28) | ((c & kClassFront) ? 1u << 30 : 0u);
+          break;
+        }
+        at += u;
+      }
+      target += G;
+    }
+  }
+  if (threadIdx.x == 0)
+    share_n = total / G + (g < total - (total / G) * G ? 1u : 0u);
+  __syncthreads();
+  const uint32_t n_mine = share_n < list_cap ? share_n : list_cap;  // (list_cap holds the worst case: see the launcher)
+
+  // The four waves take the workgroup's parts off a counter in LDS as they come free.  (One counter in memory for
+  // the whole grid cost 100 us per launch: atomics on one word take about 6 ns each on this part, whoever issues
+  // them.  Fixed shares per wave: two or three parts each, and the launch lasts as long as three.)
+  const bool first_lane = (threadIdx.x & 63u) == 0;
+  for (;;)
+  {
+    uint32_t k = 0;
+    if (first_lane)
+      k = atomicAdd(&share_next, 1u);
+    k = __builtin_amdgcn_readfirstlane(k);
+    if (k >= n_mine)
+      break;
+    asm volatile("" : "+s"(pq));
+    IT_BEGIN;
+    const uint32_t item = __builtin_amdgcn_readfirstlane(my_parts[k]);
+    const uint32_t brick = item & 0x0fffffffu, part = (item >> 28) & 3u;
+    const bool is_front = (item >> 30) & 1u;
+    const uint32_t wave = brick & 3u, tile = brick >> 2, cj = tile / p.grid_x, block_x = tile - cj * p.grid_x;
+    const int cs = p.z0 + __builtin_amdgcn_readfirstlane((int)chunks.first[cj]);
+    const int ce = cs + __builtin_amdgcn_readfirstlane((int)chunks.layers[cj]);
+    const int pl = part_layers(ce - cs);
+    const int zs = cs + (int)part * pl;  // this part's layers of the brick
+    const int ze = zs + pl < ce ? zs + pl : ce;
+#ifdef YAK_INTEGRATE_TIMING
+    const size_t it_slot = (size_t)brick * 4 + part;
+#endif
+    mask_t dead = 0, front = 0;
+    int shift = 31;
+    int ws = zs, we = ze;
+    bool stream = is_front;
+    if (refine && !is_front)
+    {
+      // the part once more, layer by layer against the fine cells
+      shift = 0;
+      while ((8 << shift) < ze - zs)
+        ++shift;
+      classify_pieces<VX>(p, block_x, wave, zs, ze, shift, dead, front);
+      if (dead == ~0ull)
+      {
+        IT_CLOCK(it_t1);
+        IT_ROW(it_slot, kBrickDead, it_t1, 0, 0);
+        continue;
+      }
+      // cut the dead pieces off both ends (the replay then stops at the first layer that matters)
+      const int first = __builtin_ctzll(~dead) >> 3, last = (63 - __builtin_clzll(~dead)) >> 3;
+      ws = zs + (first << shift);
+      we = zs + ((last + 1) << shift);
+      if (we > ze)
+        we = ze;
+      // front from the first live piece to the last: the part is streamed
+      const mask_t upto = last == 7 ? ~0ull : (1ull << ((last + 1) << 3)) - 1ull;
+      const mask_t range = upto & ~((1ull << (first << 3)) - 1ull);
+      stream = (front & range) == range;
+    }
+    IT_CLOCK(it_t1);
+    if (stream)
+    {
+      uint32_t elem;
+      int x0, y;
+      if (lane_voxels<VX>(p, block_x, wave, elem, x0, y))
+      {
+        const uint32_t lb = p.plane * 4u;
+        const rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(p.vol + (size_t)(ws - p.z0) * p.plane, 0,
+                                                             (uint32_t)(we - ws) * lb, 0x00020000);
+        walk_front_deep<VX, NT, 4>(p, rsf, elem * 4u, lb, we - ws, ballot(true), ((uint32_t)p.max_weight << 16) | 0xffffu);
+      }
+      IT_ROW(it_slot, kBrickFront, it_t1, 0, we - ws);
+      continue;
+    }
+#ifdef YAK_INTEGRATE_TIMING
+    walk_mixed<VX, NT, true>(p, coarse_lds, block_x, wave, zs, ws, we, dead, front, shift, it_t3, it_slot);
+#else
+    walk_mixed<VX, NT, true>(p, coarse_lds, block_x, wave, zs, ws, we, dead, front, shift);
+#endif
+    IT_ROW(it_slot, kBrickMixed, it_t1, it_t3, we - ws);
+  }
+#undef p
 }
 #ifdef YAK_INTEGRATE_TIMING
+extern "C" int yakhip_debug_integrate_phases(unsigned long long* out, int max_rows)
+{
+  void* at = nullptr;
+  const int n = max_rows < kItSlots ? max_rows : kItSlots;
+  if (hipDeviceSynchronize() != hipSuccess || hipGetSymbolAddress(&at, HIP_SYMBOL(g_it_phase)) != hipSuccess ||
+      hipMemcpy(out, at, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemset(at, 0, (size_t)n * 8 * sizeof(unsigned long long)) != hipSuccess)
+    return -1;
+  return n;
+}
 extern "C" int yakhip_debug_integrate_rows(unsigned long long* out, int max_rows)
 {
   void* at = nullptr;
@@ -1107,15 +1703,34 @@ extern "C" int yakhip_debug_integrate_rows(unsigned long long* out, int max_rows
 template <int VX>
 static int launch_variant(yakhip_ctx* ctx, const IntegrateParams& p, const ChunkTable& chunks, dim3 grid, bool use_static)
 {
-  const size_t lds = VX == 4 && p.grp_enable ? (size_t)p.cw * p.ch * sizeof(float) : 0;
+  const size_t coarse_lds = VX == 4 && p.grp_enable ? (size_t)p.cw * p.ch * sizeof(float) : 0;
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-  int rc = use_static ? 0 : timing_begin(ctx, &ev);  // measurement aid: one event pair around this kernel only
+  int rc = use_static ? 0 : timing_begin(ctx, &ev);  // measurement aid: one event pair around this launch's kernels
   if (rc != 0)                                       // (it may create events: not on the allocation-free path)
     return rc;
+  if (!use_static)
+    (p.two_kernels ? ctx->launches_two : ctx->launches_one) += 1;
+  if constexpr (VX == 4)
+    if (p.two_kernels)
+    {
+      const uint32_t rows_x = (grid.x * 4u + 31u) / 32u;
+      hipLaunchKernelGGL((classify_kernel<VX>), dim3(grid.x + rows_x * grid.y), dim3(256), 0, ctx->stream, p, chunks, rows_x);
+      const int per_simd = ctx->mixed_waves > 0 ? ctx->mixed_waves : kMixedWavesPerSimd;
+      const uint32_t G = (uint32_t)(ctx->num_cus * per_simd);
+      const uint32_t list_cap = (p.n_bricks * 4u + G - 1u) / G + 1u;  // (every brick live, four parts each)
+      const size_t lds2 = coarse_lds + (size_t)list_cap * sizeof(uint32_t);
+      if (ctx->nontemporal)
+        hipLaunchKernelGGL((integrate_list_kernel<VX, true>), dim3(G), dim3(256), lds2, ctx->stream, p, chunks, ctx->refine, list_cap);
+      else
+        hipLaunchKernelGGL((integrate_list_kernel<VX, false>), dim3(G), dim3(256), lds2, ctx->stream, p, chunks, ctx->refine, list_cap);
+      if ((rc = timing_end(ctx, ev)) != 0)
+        return rc;
+      return check(hipGetLastError(), "integrate_list_kernel launch");
+    }
   if (ctx->nontemporal)
-    hipLaunchKernelGGL((integrate_kernel<VX, true>), grid, dim3(256), lds, ctx->stream, p, chunks);
+    hipLaunchKernelGGL((integrate_kernel<VX, true>), grid, dim3(256), coarse_lds, ctx->stream, p, chunks);
   else
-    hipLaunchKernelGGL((integrate_kernel<VX, false>), grid, dim3(256), lds, ctx->stream, p, chunks);
+    hipLaunchKernelGGL((integrate_kernel<VX, false>), grid, dim3(256), coarse_lds, ctx->stream, p, chunks);
   if ((rc = timing_end(ctx, ev)) != 0)
     return rc;
   return check(hipGetLastError(), "integrate_kernel launch");
@@ -1131,7 +1746,7 @@ constexpr size_t kStaticMaxPixels = YAKHIP_STATIC_MAX_PIXELS;    // image of the
 constexpr size_t kStaticMaxColumns = YAKHIP_STATIC_MAX_COLUMNS;  // X * Y up to which a deep slab gets checkpoints
 constexpr size_t kStaticCoarseCap = 32768;
 constexpr size_t kStaticCellCap = 1u << 20;  // both brick-test planes (8 B per 16 x 16 pixel cell)
-constexpr size_t kStaticFrameBytes = kStaticMaxPixels * sizeof(f32x2) + kStaticCoarseCap + kStaticCellCap;
+constexpr size_t kStaticFrameBytes = kStaticMaxPixels * sizeof(f32x2) + 256u + kStaticCoarseCap + kStaticCellCap;
 constexpr size_t kStaticCkptBytes = kStaticMaxColumns * 3u * sizeof(float);
 static __device__ __align__(256) unsigned char scratch[kStaticFrameBytes + kStaticCkptBytes];
 
@@ -1180,6 +1795,25 @@ static int prepare_checkpoint(yakhip_ctx* ctx, IntegrateParams& p, int slot, int
 // All slots of one launch have the same geometry (same image size, same coarse cap).
 // ahead = true (launch_integrate_prepare): only the prepass, into the slot prepare calls take in turn, noted in
 // ctx->prepared; a later single-frame call for the same image finds it there and launches no prepass of its own.
+// Once yakhip_integrate_prepare is in use (a prepass may then run on another stream than the walks), every launch that
+// reads the context's threshold scratch leaves an event behind for the half (or halves) of it that it read, and a
+// prepass ahead of time waits for the event of the half it is about to write.  In the matched order -- prepare(f + 1)
+// beside integrate(f), each in its own half -- that event was recorded behind integrate(f - 1) and is long past;
+// any other order of calls (another image in between, a batch, a skipped prepare) is now merely slower, where it
+// used to let the prepass rewrite thresholds under a running walk.
+static int note_thr_read(yakhip_ctx* ctx, int slot /* -1: all of it */)
+{
+  if (!ctx->prepare_used)
+    return 0;
+  for (int s = 0; s < 2; ++s)
+    if (slot < 0 || slot == s)
+    {
+      YAKHIP_TRY(hipEventRecord(ctx->thr_read[s], ctx->stream));
+      ctx->thr_read_valid[s] = 1;
+    }
+  return 0;
+}
+
 static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slots, size_t coarse_cap_bytes,
                          bool use_static = false, bool ahead = false)
 {
@@ -1188,6 +1822,22 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
   {
     slots = 2, slot = ctx->prepared_next;
     ctx->prepared.valid = false;
+    if (!ctx->prepare_used)
+    {
+      // first use: the events, and one wait for everything the walks' stream holds so far (launches before this
+      // one left no event)
+      for (int s = 0; s < 2; ++s)
+        YAKHIP_TRY(hipEventCreateWithFlags(&ctx->thr_read[s], hipEventDisableTiming));
+      ctx->prepare_used = 1;
+      hipStream_t walks = ctx->main_stream_saved ? ctx->main_stream : ctx->stream;
+      if (walks != ctx->stream)
+      {
+        YAKHIP_TRY(hipEventRecord(ctx->thr_read[0], walks));
+        YAKHIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->thr_read[0], 0));
+      }
+    }
+    else if (ctx->thr_read_valid[slot])
+      YAKHIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->thr_read[slot], 0));
   }
   else if (ctx->prepared.valid)
   {
@@ -1199,6 +1849,8 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
     if (reuse)
       slots = 2, slot = ctx->prepared.slot;
   }
+  if (!ahead && !use_static)
+    ctx->thr_slot_read = reuse ? slot : -1;  // (what the launch that follows reads: note_thr_read)
   // ---- per-frame prepass into context-owned scratch: per-pixel band thresholds (8 B/pixel) and
   //      the coarse minima the group test looks up (one float per bk x bk pixel cell) ----
   int bk = 8;
@@ -1206,18 +1858,22 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
     bk *= 2;
   p.cw = (p.cols + bk - 1) / bk;
   p.ch = (p.rows + bk - 1) / bk;
-  const size_t thr_bytes = (size_t)p.rows * (size_t)p.cols * sizeof(f32x2);
+  const size_t thr_bytes = (((size_t)p.rows * (size_t)p.cols + 1u) * sizeof(f32x2) + 15u) & ~(size_t)15u;  // + the entry {-1, -1}
+  p.thr_none = (uint32_t)p.rows * (uint32_t)p.cols;
   const size_t coarse_bytes = (size_t)p.cw * p.ch * sizeof(float);
   p.ccw = (p.cols + kBrickCell - 1) / kBrickCell;
   p.cch = (p.rows + kBrickCell - 1) / kBrickCell;
   const size_t cell_bytes = (size_t)p.ccw * p.cch * sizeof(float);  // per plane
-  const size_t slot_bytes = (thr_bytes + coarse_bytes + 2u * cell_bytes + 255u) & ~(size_t)255u;
+  p.fcw = (p.cols + kFineCell - 1) / kFineCell;
+  p.fch = (p.rows + kFineCell - 1) / kFineCell;
+  const size_t fine_bytes = (size_t)p.fcw * p.fch * sizeof(float);  // per plane
+  const size_t slot_bytes = (thr_bytes + coarse_bytes + 2u * cell_bytes + 2u * fine_bytes + 255u) & ~(size_t)255u;
   if (use_static)
   {
     if (!ctx->static_scratch)
       return fail(YAKHIP_EINVAL, "integrate_static: the context holds no address of the static scratch");
     if ((size_t)p.rows * (size_t)p.cols > kStaticMaxPixels || coarse_bytes > kStaticCoarseCap ||
-        2u * cell_bytes > kStaticCellCap)
+        2u * cell_bytes + 2u * fine_bytes > kStaticCellCap)
       return fail(YAKHIP_ERANGE, "integrate_static: a %d x %d image exceeds the static scratch (at most %zu pixels)",
                   p.cols, p.rows, kStaticMaxPixels);
   }
@@ -1242,6 +1898,8 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
   p.coarse = (const float*)(base + thr_bytes);
   p.cellmin = (const float*)(base + thr_bytes + coarse_bytes);
   p.cellmax = (const float*)(base + thr_bytes + coarse_bytes + cell_bytes);
+  p.finemin = (const float*)(base + thr_bytes + coarse_bytes + 2u * cell_bytes);
+  p.finemax = (const float*)(base + thr_bytes + coarse_bytes + 2u * cell_bytes + fine_bytes);
   if (ahead)
     p.ckpt = nullptr;
   else
@@ -1257,11 +1915,15 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
     const uint32_t cell_blocks = (uint32_t)((p.cw * p.ch + 3) / 4);
     const uint32_t ckpt_blocks = p.ckpt ? (p.plane + 255u) / 256u : 0u;
     const uint32_t brick_blocks = (uint32_t)((p.ccw * p.cch + 3) / 4);
-    hipLaunchKernelGGL(prepass_kernel, dim3(thr_blocks + cell_blocks + brick_blocks + ckpt_blocks), dim3(256), 0,
-                       ctx->stream, p.dists, p.dists_pitch, p.rows, p.cols, p.trunc_hi, (f32x2*)base,
+    const uint32_t fine_blocks = (uint32_t)((p.fcw * p.fch + 255) / 256);
+    // (one more workgroup sums up the class bytes of the launch before this one: see prepass_kernel)
+    const uint32_t stats_blocks = !ahead && !use_static && ctx->classes && ctx->classes_n != 0 && ctx->stats_host ? 1u : 0u;
+    hipLaunchKernelGGL(prepass_kernel, dim3(thr_blocks + cell_blocks + brick_blocks + fine_blocks + stats_blocks + ckpt_blocks),
+                       dim3(256), 0, ctx->stream, p.dists, p.dists_pitch, p.rows, p.cols, p.trunc_hi, (f32x2*)base,
                        (float*)(base + thr_bytes), p.cw, p.ch, bk, thr_blocks_x, thr_blocks, ckpt_blocks, p,
                        const_cast<float*>(p.ckpt), const_cast<float*>(p.cellmin), const_cast<float*>(p.cellmax), p.ccw,
-                       p.cch, cell_blocks);
+                       p.cch, cell_blocks, brick_blocks, fine_blocks, (const uint32_t*)ctx->classes, (uint32_t)ctx->classes_n,
+                       ctx->classes_seq, ctx->stats_host);
     YAKHIP_TRY(hipGetLastError());
   }
   if (ahead)
@@ -1304,6 +1966,86 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
     p.brick_enable = ctx->brick_test && p.fx > 0.f && p.fy > 0.f && p.cols < 32768 && p.rows < 32768 &&
                      std::isfinite(P) && std::isfinite(f) && std::isfinite(p.cx) && std::isfinite(p.cy);
   }
+  return 0;
+}
+
+// Whether a launch goes through the two kernels (classify_kernel / integrate_list_kernel), and their memory: a class
+// byte per wave brick, padded with zeros to a multiple of 1024, and the column checkpoints.
+static int prepare_list(yakhip_ctx* ctx, IntegrateParams& p, uint64_t wave_bricks, uint32_t blocks_x, int vx, bool use_static)
+{
+  p.classes = nullptr;
+  p.n_bricks = 0;
+  p.grid_x = blocks_x;
+  p.cptab = nullptr;
+  p.cp_stride = p.cp_count = 0;
+  p.two_kernels = 0;
+  // (the entry point that allocates nothing keeps to one kernel: the checkpoints alone are 50 MB for a 512^2 plane)
+  if (use_static || !ctx->defer_mixed || !p.brick_enable || vx != 4 || (ctx->defer_mixed == 1 && wave_bricks < kDeferMinWaves) ||
+      wave_bricks >= (1u << 28))
+    return 0;
+  // Which launch: the two kernels pay where mixed bricks are many and front bricks few (an orbit frame at 512^3:
+  // 0.109 -> 0.093 ms); a frame that is mostly free space streams best from the one-kernel grid (the wall scene:
+  // 0.182 against 0.25 ms).  The launcher goes by what the brick test found in an earlier frame of this volume --
+  // the previous launch's class bytes, summed up by this launch's prepass into pinned memory and read here without
+  // waiting, so it is two frames old or older -- and starts with one kernel.  Either way the voxels are the same.
+  // A caller that enqueues frame after frame without ever waiting gets one kernel, as before: the findings must be
+  // those of one of the last four launches to count (a frame loop that waits once per frame, as tracking does, sees
+  // the launch before the previous one).
+  bool two = ctx->defer_mixed == 2;
+  ctx->launch_seq += 1;
+  if (ctx->defer_mixed == 1 && ctx->stats_host)
+  {
+    const volatile uint32_t* st = ctx->stats_host;
+    const uint32_t front = st[0], mixed = st[1], n = st[2], seq = st[3];
+    two = n == wave_bricks && ctx->launch_seq - seq <= 4u && mixed >= 1024u && front <= 2u * mixed;
+  }
+  const size_t bytes_cls = ((size_t)wave_bricks + 1023u) & ~(size_t)1023u;
+  if (ctx->classes_bytes < bytes_cls)
+  {
+    if (ctx->classes)
+    {
+      YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
+      YAKHIP_TRY(hipFree(ctx->classes));
+      ctx->classes = nullptr;
+      ctx->classes_bytes = 0;
+    }
+    YAKHIP_TRY(hipMalloc((void**)&ctx->classes, bytes_cls));
+    ctx->classes_bytes = bytes_cls;
+    ctx->classes_n = 0;
+  }
+  if (ctx->classes_n != wave_bricks)  // (the padding behind the last brick must read as dead)
+  {
+    YAKHIP_TRY(hipMemsetAsync(ctx->classes, 0, ctx->classes_bytes, ctx->stream));
+    ctx->classes_n = wave_bricks;
+  }
+  p.classes = ctx->classes;
+  p.n_bricks = (uint32_t)wave_bricks;
+  ctx->classes_seq = ctx->launch_seq;  // (the launch these class bytes will be of)
+  if (!two)
+    return 0;
+  p.two_kernels = 1;
+  // column checkpoints every cp_stride layers, at most 256 MiB of them
+  const int layers = p.z1 - p.z0;
+  int stride = kCheckpointStride;
+  while ((size_t)((layers + stride - 1) / stride) * 3u * p.plane * sizeof(float) > ((size_t)256 << 20) && stride < layers)
+    stride *= 2;
+  const int count = (layers + stride - 1) / stride;
+  const size_t bytes = (size_t)count * 3u * p.plane * sizeof(float);
+  if (ctx->cptab_bytes < bytes)
+  {
+    if (ctx->cptab)
+    {
+      YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
+      YAKHIP_TRY(hipFree(ctx->cptab));
+      ctx->cptab = nullptr;
+      ctx->cptab_bytes = 0;
+    }
+    YAKHIP_TRY(hipMalloc((void**)&ctx->cptab, bytes));
+    ctx->cptab_bytes = bytes;
+  }
+  p.cptab = ctx->cptab;
+  p.cp_stride = stride;
+  p.cp_count = count;
   return 0;
 }
 
@@ -1483,15 +2225,23 @@ int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in, bool use_stat
   const dim3 grid(blocks_x, chunk_table(ctx, p, chunk, 8, &chunks));
   if (grid.y == 0)
     return fail(YAKHIP_ERANGE, "integrate: the volume needs more than %d z-chunks of at most 2 GiB", kMaxChunks);
+  if ((rc = prepare_list(ctx, p, (uint64_t)grid.x * grid.y * 4u, grid.x, vx, use_static)) != 0)
+    return rc;
   switch (vx)
   {
     case 4:
-      return launch_variant<4>(ctx, p, chunks, grid, use_static);
+      rc = launch_variant<4>(ctx, p, chunks, grid, use_static);
+      break;
     case 2:
-      return launch_variant<2>(ctx, p, chunks, grid, use_static);
+      rc = launch_variant<2>(ctx, p, chunks, grid, use_static);
+      break;
     default:
-      return launch_variant<1>(ctx, p, chunks, grid, use_static);
+      rc = launch_variant<1>(ctx, p, chunks, grid, use_static);
+      break;
   }
+  if (rc == 0 && !use_static)
+    rc = note_thr_read(ctx, ctx->thr_slot_read);
+  return rc;
 }
 
 int launch_integrate_prepare(yakhip_ctx* ctx, const IntegrateParams& p_in)
@@ -1540,7 +2290,7 @@ __global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchPara
 #pragma unroll
   for (int k = 0; k < K; ++k)
   {
-    cls[k] = p.brick_enable ? classify_brick<VX, 64>(bp.f[k], zs, ze) : kBrickMixed;
+    cls[k] = p.brick_enable ? classify_brick<VX, 64>(bp.f[k], blockIdx.x, zs, ze) : kBrickMixed;
     any_mixed = any_mixed || cls[k] == kBrickMixed;
     all_dead = all_dead && cls[k] == kBrickDead;
   }
@@ -1565,7 +2315,7 @@ __global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchPara
 
   uint32_t elem;  // x + y*X of the lane's first voxel; X % VX == 0 so no row straddle
   int x0, y;
-  if (!lane_voxels<VX>(p, elem, x0, y))
+  if (!lane_voxels<VX>(p, blockIdx.x, threadIdx.x >> 6, elem, x0, y))
     return;
   const mask_t active = ballot(true);
 
@@ -1772,6 +2522,8 @@ int launch_integrate_batch(yakhip_ctx* ctx, const IntegrateParams* frames, int n
         break;
     }
     if (rc != 0)
+      return rc;
+    if ((rc = note_thr_read(ctx, -1)) != 0)
       return rc;
     done += k;
   }

@@ -48,6 +48,21 @@ struct yakhip_ctx
   int prepared_next;   // slot the next prepare call writes (0 / 1 in turn)
   void* ckpt;          // scratch: column positions at layer z0 of a deep slab (integrate.hip, checkpoint_kernel)
   size_t ckpt_bytes;
+  uint8_t* classes;    // between the two kernels of a large launch: a class byte per wave brick (IntegrateParams::classes)
+  size_t classes_bytes;
+  uint64_t classes_n;  // ... bricks of the last launch that used it (the bytes behind them are zero)
+  unsigned long long launches_one, launches_two;  // yakhip_ctx_launch_counts
+  uint32_t launch_seq, classes_seq;  // launches that could have used it so far; the one whose classes it holds
+  uint32_t* stats_host; // pinned: {front bricks, mixed bricks, wave bricks, launch number} of an earlier launch (integrate.hip, prepare_list)
+  float* cptab;        // ... and the column checkpoints (IntegrateParams::cptab)
+  size_t cptab_bytes;
+  int defer_mixed;     // 1 (default): mixed bricks of large launches go through that list; 0: walked where they are classified
+  int mixed_waves;     // waves per SIMD of the second kernel (0 = default)
+  int refine;          // the second kernel looks at a mixed brick again, in up to eight pieces along z (default) / walks it whole
+  int num_cus;
+  hipEvent_t thr_read[2];  // after the last launch that read slot 0 / 1 of thr (recorded once yakhip_integrate_prepare is in use)
+  int prepare_used, thr_read_valid[2];
+  int thr_slot_read;   // half of thr the launch being set up reads (-1: all of it)
   uint32_t* brick_stats; // device counters {mixed, dead, front, -}, allocated by the "brick_stats" option
   void* static_scratch;  // this device's copy of integrate.hip's file-scope scratch array (yakhip_integrate_static)
   void* icp_scratch;   // ICP: workgroup partials + the reduced 33 values (device)
@@ -94,12 +109,24 @@ struct IntegrateParams
 {
   uint32_t* vol;         // layer z0 of the slab
   const uint8_t* dists;  // half image, row pitch in bytes
-  const f32x2* thr;      // per-pixel {A2, B2} band thresholds, dense rows x cols
+  const f32x2* thr;      // per-pixel {A2, B2} band thresholds, dense rows x cols, and one more entry {-1, -1}
+  uint32_t thr_none;     // ... its index (rows * cols): what a voxel that sees no pixel gathers
   const float* coarse;   // coarse minima of A2 (group test), cw x ch cells
   const float* ckpt;     // nullptr, or camera-space x | y | z of every column at layer z0 (3 planes of X*Y floats)
   const float* cellmin;  // brick test: min of A2 / max of the B2 word over each 16 x 16 pixel cell, ccw x cch cells
   const float* cellmax;
   int ccw, cch;
+  const float* finemin;  // the same two planes over 4 x 4 pixel cells, fcw x fch: the second look at a mixed brick, piece by piece
+  const float* finemax;
+  int fcw, fch;
+  uint8_t* classes;      // nullptr, or where the brick test leaves its findings: a byte per wave brick (parts to do | 0x80 if
+                         // front; 0 = dead), brick = (chunk * grid_x + plane tile) * 4 + wave
+  int two_kernels;       // 0: one kernel, every workgroup walks its own bricks.  1: classify_kernel leaves the classes,
+                         // integrate_list_kernel deals the live bricks' parts out evenly (integrate.hip)
+  uint32_t n_bricks, grid_x;  // wave bricks of the launch; plane tiles (workgroups of the one-kernel grid per chunk)
+  float* cptab;          // two kernels: camera-space positions of every column at the layers z0 + k * cp_stride, k < cp_count
+  int cp_stride, cp_count;  // (plane floats of x, then y, then z per k), written by extra workgroups of the first kernel, so
+                         // that the second starts a part from the checkpoint below it instead of replaying from layer 0
   uint32_t* bricks;      // nullptr, or the slab's surface map: one bit per 16^3 brick, bricks_x x bricks_y x bricks_z,
   int bricks_x, bricks_y, bricks_z;  // then (bricks_words 32-bit words on) one bit per cell of 4 x 4 x 4 bricks
   uint32_t bricks_words;
