@@ -97,18 +97,22 @@ def next_rows(ctx, torch, capi, synth, with_cpu):
     desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT, surface_map=smap.data_ptr())
     frames, keep = [], []
     for f in range(0, 300, 38):
-        depth, R, t = synth.scene_s2(f)
+        depth, R, t = synth.scene_s2(f, noise_mm=1.0)  # (the frames of the `orbit_views` row)
         d = torch.from_numpy(depth.view(np.int16)).cuda()
         dd = torch.empty_like(d)
         ctx.compute_dists(d.data_ptr(), cols * 2, dd.data_ptr(), cols * 2, rows, cols, intr)
         keep.append((d, dd))
         frames.append((dd.data_ptr(), cols * 2, rows, cols, R.reshape(-1), t, intr))
 
-    def timed(fn, reps):
+    def timed(fn, reps, wait=False):
         fn()
+        if wait:
+            torch.cuda.synchronize()
         ctx.set_option("kernel_timing", 1)
         for _ in range(reps):
             fn()
+            if wait:  # (a caller that waits once per call: see orbit_views_row)
+                torch.cuda.synchronize()
         ms, launches = ctx.kernel_time()
         ctx.set_option("kernel_timing", 0)
         return ms / reps
@@ -118,7 +122,13 @@ def next_rows(ctx, torch, capi, synth, with_cpu):
     # command belongs to the headline workload (the rocprofv3 average of that kernel stays comparable).
     ctx.integrate_batch(desc, frames[:4])
     ctx.integrate_batch(desc, frames[4:])
-    out["integrate_batch_k4_s2_ms_per_frame"] = round(timed(lambda: ctx.integrate_batch(desc, frames[:4]), 5) / 4, 4)
+    # (the batched entry point on the first four frames of the `orbit_views` row: where the brick test found mostly surface
+    #  in the last launches, the library runs the batch as single-frame launches -- the voxels are the same by definition)
+    c0 = ctx.launch_counts()
+    out["integrate_batch_k4_s2_ms_per_frame"] = round(timed(lambda: ctx.integrate_batch(desc, frames[:4]), 5, wait=True) / 4, 4)
+    c1 = ctx.launch_counts()
+    out["integrate_batch_k4_s2_ran_as"] = ("single-frame launches: %s" % {k: c1[k] - c0[k] for k in c1}
+                                           if sum(c1.values()) > sum(c0.values()) else "integrate_batch_kernel<4> sweeps")
 
     # raycast from orbit poses (cam2vol = inverse of vol2cam): along the volume's z axis (views 0, 150) and
     # oblique (37, 100, 222), with the surface map and without it
@@ -302,13 +312,21 @@ def orbit_views_row(ctx, torch, capi, synth):
         ctx.integrate(desc, ptr, cols * 2, rows, cols, R, t, intr)
     bricks = ctx.brick_stats()
     ctx.set_option("brick_stats", 0)
+    # (a wait per frame, as a tracking loop has one: the library chooses between its one-kernel and its two-kernel launch
+    #  by what the brick test found in the last few frames, and a caller that never waits is given one kernel)
+    for ptr, R, t in views:
+        ctx.integrate(desc, ptr, cols * 2, rows, cols, R, t, intr)
+        torch.cuda.synchronize()
+    counts0 = ctx.launch_counts()
     ctx.set_option("kernel_timing", 1)
     reps = 5
     for _ in range(reps):
         for ptr, R, t in views:
             ctx.integrate(desc, ptr, cols * 2, rows, cols, R, t, intr)
+            torch.cuda.synchronize()
     ms, _ = ctx.kernel_times(reps * len(views))
     ctx.set_option("kernel_timing", 0)
+    counts1 = ctx.launch_counts()
     per_view = [sum(ms[i::len(views)]) / reps for i in range(len(views))]
     mean_ms = sum(per_view) / len(per_view)
     mean_upd = sum(updated) / len(updated)
@@ -321,6 +339,10 @@ def orbit_views_row(ctx, torch, capi, synth):
             "algorithmic_GBps": round(alg / (mean_ms * 1e-3) / 1e9, 1),
             "frac_of_hbm_peak": round(alg / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "wave_bricks": {k: round(v / total, 4) for k, v in bricks.items()},
+            "launches": {k: counts1[k] - counts0[k] for k in counts1},
+            "kernels": "yakhip::classify_kernel<4> + yakhip::integrate_list_kernel<4, true> (two kernels: one event pair around "
+                       "both) or yakhip::integrate_kernel<4, true>, see `launches`",
+            "valu_instructions": load_traffic("integrate_orbit_views_valu"),
             "note": "bound by the per-voxel path of the bricks that hold surface, not by HBM: only updated voxels "
                     "count as algorithmic bytes (SURVEY.md 8d)"}
 
@@ -391,7 +413,11 @@ def run_c5(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, e
     K = len(frames)
 
     def step():
+        # one wait per sweep, as a rig that hands over K frames at a time has: the library chooses between one sweep
+        # of K frames and K single-frame launches by what the brick test found in the last few launches (the voxels
+        # are the same), and a caller that never waits is given the sweep
         ctx.integrate_batch(held, frames)
+        torch.cuda.synchronize()
 
     def sync():
         if dist is not None:
@@ -410,15 +436,21 @@ def run_c5(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, e
     for _ in range(args.warmup):
         step()
     sync()
+    ctx.kernel_time()  # (restarts the accumulation: what follows are the timed sweeps' launches only)
+    counts0 = ctx.launch_counts()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    series, _ = ctx.kernel_times(1 + args.warmup + args.steps)
+    kernel_total_ms, kernel_launches = ctx.kernel_time()
+    counts1 = ctx.launch_counts()
     ctx.set_option("kernel_timing", 0)
-    timed = series[1 + args.warmup:]
-    kernel_ms = sum(timed) / max(len(timed), 1)
+    kernel_ms = kernel_total_ms / max(args.steps, 1)  # per sweep, whatever launches it was made of
+    single_launches = sum(counts1.values()) - sum(counts0.values())
+    sweep_kernel = ("yakhip::integrate_batch_kernel<4, true>" if single_launches == 0 else
+                    "%d x (yakhip::classify_kernel<4> + yakhip::integrate_list_kernel<4, true>)" % K
+                    if counts1["two_kernels"] - counts0["two_kernels"] == K * args.steps else "mixed: see launches_per_sweep")
 
     # marching cubes over the slab (count, scan, emit), blocking calls
     ntri = ctx.marching_cubes(held, 2, vs[0])
@@ -478,10 +510,14 @@ def run_c5(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, e
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": load_traffic("integrate_batch_c5_rank%d_of_%d" % (rank, world)),
-                         "kernel": "yakhip::integrate_batch_kernel<4, true>", "kernel_ms": round(kernel_ms, 5),
+                         "kernel": sweep_kernel, "kernel_ms": round(kernel_ms, 5),
+                         "launches_per_sweep": {"bracketed_kernel_launches": round(kernel_launches / max(args.steps, 1), 2),
+                                                "single_frame_calls_as_one_kernel": (counts1["one_kernel"] - counts0["one_kernel"]) / max(args.steps, 1),
+                                                "single_frame_calls_as_two_kernels": (counts1["two_kernels"] - counts0["two_kernels"]) / max(args.steps, 1)},
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "rank 0's slab; bound by the per-voxel path of the bricks that hold surface, not by HBM "
-                                 "(only touched voxels count as algorithmic bytes)"},
+                         "note": "rank %d's slab, kernel time per sweep of %d frames; bound by the per-voxel path of the bricks "
+                                 "that hold surface, not by HBM (only touched voxels count as algorithmic bytes, once per "
+                                 "sweep)" % (rank, K)},
             "marching_cubes": {"ms_per_extraction_slowest_rank": round(mc_ms, 4),
                                "ms_per_extraction_without_surface_map": round(mc_plain_ms, 4), "triangles": ntri_total,
                                "Gvox_per_s_per_gpu": round(visited / (mc_ms * 1e-3) / 1e9, 1),

@@ -65,14 +65,18 @@ def main():
     def sequential():
         for fr in frames:
             ctx.integrate(held, *fr)
+    ctx.set_option("defer_mixed", 0)
     ms_seq = timed(sequential, args.reps)
+    ctx.set_option("defer_mixed", 2)
+    ms_seq2 = timed(sequential, args.reps)
+    ctx.set_option("defer_mixed", 1)
     voxels = layers * n * n
     touched = int((vol.view(layers, n * n)[:, :] >> 16 != 0).sum().item())
     print("rank %d of %d of a %d^3 volume: slab [%d, %d) + 1 = %.2f GiB, voxel %.2f mm" % (
         args.rank, args.world, n, z0, z1, voxels * 4 / 2 ** 30, vs[0] * 1e3))
     print("  4 cameras, one sweep (integrate_batch): %.3f ms = %.3f ms per frame, %.0f Gvox/s visited; 4 single-frame calls: "
-          "%.3f ms; %d voxels touched (%.1f %%)" % (ms_batch, ms_batch / 4, 4 * voxels / ms_batch / 1e6, ms_seq, touched,
-                                                    100.0 * touched / voxels))
+          "%.3f ms as one kernel each, %.3f ms as two; %d voxels touched (%.1f %%)" % (ms_batch, ms_batch / 4, 4 * voxels / ms_batch / 1e6, ms_seq,
+                                                                                      ms_seq2, touched, 100.0 * touched / voxels))
     # what the wave bricks of each camera are (the single-frame kernel counts them; the sweep classifies the same bricks)
     ctx.set_option("brick_stats", 1)
     ctx.brick_stats()

@@ -17,7 +17,7 @@ rows.sort()
 d=collections.defaultdict(list)
 gaps=[]
 for i,(s,e,n) in enumerate(rows):
-    if "integrate" in n or "prepass" in n or "classify" in n:
+    if "integrate" in n or "prepass" in n or "classify" in n or "checkpoint" in n:
         d[n.split("(")[0][-50:]].append(e-s)
     if "integrate_mixed_kernel" in n and i>0 and "integrate_kernel" in rows[i-1][2]:
         gaps.append(s-rows[i-1][1])

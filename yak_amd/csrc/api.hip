@@ -156,6 +156,7 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->stats_host = nullptr;
   ctx->launch_seq = ctx->classes_seq = 0;
   ctx->launches_one = ctx->launches_two = 0;
+  memset(ctx->seq_signature, 0, sizeof(ctx->seq_signature));
   ctx->cptab = nullptr;
   ctx->cptab_bytes = 0;
   ctx->defer_mixed = 1;
@@ -931,6 +932,7 @@ static int fill_integrate_params(IntegrateParams& p, const yakhip_volume* vol, c
   if (!(vol->trunc_dist > 0.f))
     return fail(YAKHIP_EINVAL, "integrate: trunc_dist must be positive");
 
+  memset(&p, 0, sizeof(p));  // (everything the launcher fills in later starts as "none")
   p.vol = (uint32_t*)vol->data;
   p.bricks = (uint32_t*)vol->surface_map;
   p.bricks_x = (vol->dims[0] + 15) >> 4;

@@ -44,7 +44,7 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kDefaultTileShift = 6;  // wave footprint in a layer, see lane_voxels()
 constexpr int kMixedWavesPerSimd = 5;  // size of integrate_list_kernel's grid: workgroups per CU
-constexpr uint32_t kDeferMinWaves = 8192;  // launches of fewer wave bricks than this walk their mixed bricks in place
+constexpr uint64_t kTwoKernelMinVoxels = 1ull << 25;  // smaller slabs are one kernel unless "defer_mixed" is 2
 constexpr int kPartLayers = 8;         // a listed brick is walked in parts of this many layers (at most four parts)
 constexpr int kCheckpointStride = 32;  // layers between the column checkpoints of a launch with a list
 // layers per part of a brick of `layers` layers: kPartLayers, or what makes four parts of a longer brick (even)
@@ -1360,8 +1360,22 @@ __device__ __forceinline__ void checkpoint_table(const IntegrateParams& p, uint3
         A.z[k][h] = dot3(p.R[6], p.R[7], p.R[8], vxx, vxy, 0.f) + p.t[2];
       }
     }
-  if (!p.ckpt)
-    for (int i = 0; i < p.z0; ++i)  // (a slab that starts a few layers up and has no closed-form checkpoint)
+  if (p.cp_ffwd)
+  {
+    // a deep slab: the positions at z0 in closed form (ffwd.hpp: bit for bit the z0 rounded additions), as
+    // checkpoint_column has them for the one-kernel launch
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+      {
+        A.x[k][h] = yak_ffwd_accumulate(A.x[k][h], zsx, p.z0);
+        A.y[k][h] = yak_ffwd_accumulate(A.y[k][h], zsy, p.z0);
+        A.z[k][h] = yak_ffwd_accumulate(A.z[k][h], zsz, p.z0);
+      }
+  }
+  else if (!p.ckpt)
+    for (int i = 0; i < p.z0; ++i)  // (a slab that starts a few layers up)
       advance<4>(A, A, sx, sy, sz);
   float* at = p.cptab + col;
   for (int k = 0; k < p.cp_count; ++k, at += 3u * p.plane)
@@ -1477,18 +1491,21 @@ __global__ __launch_bounds__(256, 4) void integrate_kernel(const IntegrateParams
 constexpr uint32_t kClassUnits = 7u, kClassFront = 0x80u;  // a class byte: parts to do (0 = dead) | front
 
 template <int VX>
-__global__ __launch_bounds__(256) void classify_kernel(const IntegrateParams p, const ChunkTable chunks, uint32_t rows_x)
+__global__ __launch_bounds__(256) void classify_kernel(const IntegrateParams p, const ChunkTable chunks, uint32_t rows_x,
+                                                       uint32_t cp_rows)
 {
   static_assert(VX == 4, "the two-kernel launch is for the 16-byte layout");
-  // the first grid_x workgroups write the column checkpoints (dispatched first: the launch's longest jobs): lane = four
-  // columns, positions as the walk forms and advances them (tsdf_volume.cu:69-76)
-  if (blockIdx.x < p.grid_x)
+  // A slab that starts at layer 0 gets its column checkpoints from here, for every column, by cp_rows workgroups in
+  // front of the others (dispatched first: the launch's longest jobs, 512 steps one after the other; they run beside
+  // the brick tests, which leave the vector units idle).  A deep slab's start from closed-form positions costs
+  // more per column: checkpoint_tiles_kernel makes them afterwards, for the columns that need them.
+  if (blockIdx.x < cp_rows)
   {
     checkpoint_table(p, (blockIdx.x * 256u + threadIdx.x) * 4u);
     return;
   }
-  // then rows_x workgroups per chunk, 32 wave bricks each
-  const uint32_t id = blockIdx.x - p.grid_x;
+  // rows_x workgroups per chunk, 32 wave bricks each
+  const uint32_t id = blockIdx.x - cp_rows;
   const uint32_t cj = id / rows_x, in_chunk = (id - cj * rows_x) * 32u + (threadIdx.x >> 3);
   const int zs = p.z0 + __builtin_amdgcn_readfirstlane((int)chunks.first[cj]);
   const int ze = zs + __builtin_amdgcn_readfirstlane((int)chunks.layers[cj]);
@@ -1508,6 +1525,29 @@ __global__ __launch_bounds__(256) void classify_kernel(const IntegrateParams p, 
     if (p.brick_stats)  // measurement aid, off by default
       atomicAdd(&p.brick_stats[cls], 1u);
   }
+}
+
+// Between the two: the column checkpoints, for the columns that need them -- those of a wave footprint with a mixed
+// brick in some chunk (front bricks are streamed: no positions).  One workgroup per plane tile, lane = four columns,
+// positions as the walk forms and advances them (tsdf_volume.cu:69-76), stored every cp_stride layers.  On a slab
+// of configuration 5 a fifth of the columns; the table for all of them was 200 MB written per frame.
+template <int VX>
+__global__ __launch_bounds__(256) void checkpoint_tiles_kernel(const IntegrateParams p, uint32_t n_chunks)
+{
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  bool mixed = false;
+  for (uint32_t cj = lane; cj < n_chunks; cj += 64u)
+  {
+    const uint32_t c = p.classes[((size_t)cj * p.grid_x + blockIdx.x) * 4u + wave];
+    mixed = mixed || ((c & kClassUnits) != 0 && (c & kClassFront) == 0);
+  }
+  if (ballot(mixed) == 0)
+    return;
+  uint32_t elem;
+  int x0, y;
+  if (!lane_voxels<VX>(p, blockIdx.x, wave, elem, x0, y))
+    return;
+  checkpoint_table(p, elem);
 }
 
 template <int VX, bool NT>
@@ -1714,7 +1754,10 @@ static int launch_variant(yakhip_ctx* ctx, const IntegrateParams& p, const Chunk
     if (p.two_kernels)
     {
       const uint32_t rows_x = (grid.x * 4u + 31u) / 32u;
-      hipLaunchKernelGGL((classify_kernel<VX>), dim3(grid.x + rows_x * grid.y), dim3(256), 0, ctx->stream, p, chunks, rows_x);
+      const uint32_t cp_rows = p.cp_ffwd ? 0u : grid.x;
+      hipLaunchKernelGGL((classify_kernel<VX>), dim3(cp_rows + rows_x * grid.y), dim3(256), 0, ctx->stream, p, chunks, rows_x, cp_rows);
+      if (p.cp_ffwd)
+        hipLaunchKernelGGL((checkpoint_tiles_kernel<VX>), dim3(grid.x), dim3(256), 0, ctx->stream, p, grid.y);
       const int per_simd = ctx->mixed_waves > 0 ? ctx->mixed_waves : kMixedWavesPerSimd;
       const uint32_t G = (uint32_t)(ctx->num_cus * per_simd);
       const uint32_t list_cap = (p.n_bricks * 4u + G - 1u) / G + 1u;  // (every brick live, four parts each)
@@ -1795,6 +1838,90 @@ static int prepare_checkpoint(yakhip_ctx* ctx, IntegrateParams& p, int slot, int
 // All slots of one launch have the same geometry (same image size, same coarse cap).
 // ahead = true (launch_integrate_prepare): only the prepass, into the slot prepare calls take in turn, noted in
 // ctx->prepared; a later single-frame call for the same image finds it there and launches no prepass of its own.
+// what the findings belong to: the slab's extent (they carry over between the launches of a volume whatever their chunking)
+static uint32_t volume_signature(const IntegrateParams& p)
+{
+  uint32_t h = 2166136261u;
+  for (uint32_t v : { (uint32_t)p.X, (uint32_t)p.Y, (uint32_t)p.z0, (uint32_t)p.z1 })
+    h = (h ^ v) * 16777619u;
+  return h | 1u;
+}
+
+// The brick test's findings of a recent launch of this volume, if there are any: shares of front and of mixed wave bricks.
+static bool recent_findings(const yakhip_ctx* ctx, const IntegrateParams& p, double* front, double* mixed)
+{
+  if (!ctx->stats_host)
+    return false;
+  const volatile uint32_t* st = ctx->stats_host;
+  const uint32_t f = st[0], m = st[1], n = st[2], seq = st[3];
+  if (n == 0 || ctx->launch_seq - seq > 4u || ctx->seq_signature[seq & 7u] != volume_signature(p))
+    return false;
+  *front = (double)f / n;
+  *mixed = (double)m / n;
+  return true;
+}
+
+// widest vector the layout allows: rows must not straddle a lane's group and the slab base,
+// every row start and every layer start must be aligned to the vector size
+static int widest_vector(const yakhip_ctx* ctx, const IntegrateParams& p)
+{
+  const uintptr_t base = (uintptr_t)p.vol;
+  int vx = 1;
+  if (p.X % 4 == 0 && base % 16 == 0)
+    vx = 4;
+  else if (p.X % 2 == 0 && base % 8 == 0)
+    vx = 2;
+  if (ctx->force_vx > 0 && ctx->force_vx < vx)
+    vx = ctx->force_vx;
+  return vx;
+}
+
+// P = largest |camera coordinate| in the slab, f = larger focal length: what the culling tests' margins are made of
+static void pose_extent(const IntegrateParams& p, float* P_out, float* f_out)
+{
+  float P = 0.f;
+  for (int i = 0; i < 3; ++i)
+  {
+    const float ext = fabsf(p.R[3 * i + 0]) * p.vsx * (float)p.X + fabsf(p.R[3 * i + 1]) * p.vsy * (float)p.Y +
+                      fabsf(p.R[3 * i + 2]) * p.vsz * (float)p.z1 + fabsf(p.t[i]);
+    P = fmaxf(P, ext);
+  }
+  *P_out = P;
+  *f_out = fmaxf(fabsf(p.fx), fabsf(p.fy));
+}
+
+// the brick test assumes an ordinary pinhole (positive focal lengths, image below 32k px) and a finite pose
+static bool brick_test_allowed(const yakhip_ctx* ctx, const IntegrateParams& p)
+{
+  float P, f;
+  pose_extent(p, &P, &f);
+  return ctx->brick_test && p.fx > 0.f && p.fy > 0.f && p.cols < 32768 && p.rows < 32768 && std::isfinite(P) && std::isfinite(f) &&
+         std::isfinite(p.cx) && std::isfinite(p.cy);
+}
+
+// Which launch (decided before anything is enqueued, so that the prepass does what that launch needs and no more):
+// the two kernels pay where mixed bricks are many and front bricks few (an orbit frame at 512^3: 0.109 -> 0.093 ms); a
+// frame that is mostly free space streams best from the one-kernel grid (the wall scene: 0.182 against 0.25 ms).  The
+// launcher goes by what the brick test found in an earlier frame of this volume -- the previous launch's class
+// bytes, summed up by this launch's prepass into pinned memory and read here without waiting, so it is two frames
+// old or older -- and starts with one kernel.  Either way the voxels are the same.  A caller that enqueues frame after
+// frame without ever waiting gets one kernel, as before: the findings must be those of one of the last four launches
+// to count (a frame loop that waits once per frame, as tracking does, sees the launch before the previous one).
+// pose_known = false (yakhip_integrate_prepare): whether the frame being prepared is likely to go that way.
+static bool want_two_kernels(const yakhip_ctx* ctx, const IntegrateParams& p, int vx, bool use_static, bool pose_known = true)
+{
+  // (the entry point that allocates nothing keeps to one kernel: the checkpoints alone are 50 MB for a 512^2 plane)
+  if (use_static || !ctx->defer_mixed || vx != 4 || (pose_known && !brick_test_allowed(ctx, p)) || (!pose_known && !ctx->brick_test))
+    return false;
+  const uint64_t voxels = (uint64_t)p.plane * (uint64_t)(p.z1 - p.z0);
+  if (voxels / 256u >= (1u << 26))  // (wave bricks are numbered in 28 bits; chunks are at least 8 layers)
+    return false;
+  if (ctx->defer_mixed == 2)
+    return true;
+  double front = 0, mixed = 0;
+  return voxels >= kTwoKernelMinVoxels && recent_findings(ctx, p, &front, &mixed) && mixed >= 0.03 && front <= 2.0 * mixed;
+}
+
 // Once yakhip_integrate_prepare is in use (a prepass may then run on another stream than the walks), every launch that
 // reads the context's threshold scratch leaves an event behind for the half (or halves) of it that it read, and a
 // prepass ahead of time waits for the event of the half it is about to write.  In the matched order -- prepare(f + 1)
@@ -1814,8 +1941,11 @@ static int note_thr_read(yakhip_ctx* ctx, int slot /* -1: all of it */)
   return 0;
 }
 
+// two: the launch that follows is the two-kernel one -- the prepass then fills the fine cells as well and leaves the
+// closed-form column checkpoints of a deep slab out (checkpoint_tiles_kernel makes the ones it needs); ahead of time
+// (no launch follows yet) the same for a frame that is likely to go that way.
 static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slots, size_t coarse_cap_bytes,
-                         bool use_static = false, bool ahead = false)
+                         bool use_static = false, bool ahead = false, bool two = false)
 {
   bool reuse = false;
   if (ahead)
@@ -1844,7 +1974,7 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
     // (any other use of the scratch overwrites what was prepared)
     reuse = !use_static && slots == 1 && ctx->prepared.dists == (const void*)p.dists && ctx->prepared.pitch == p.dists_pitch &&
             ctx->prepared.rows == p.rows && ctx->prepared.cols == p.cols && ctx->prepared.trunc_hi == p.trunc_hi &&
-            (p.z0 < kCheckpointFrom || !ctx->checkpoint);
+            (two ? ctx->prepared.fine : (p.z0 < kCheckpointFrom || !ctx->checkpoint));
     ctx->prepared.valid = false;
     if (reuse)
       slots = 2, slot = ctx->prepared.slot;
@@ -1900,7 +2030,7 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
   p.cellmax = (const float*)(base + thr_bytes + coarse_bytes + cell_bytes);
   p.finemin = (const float*)(base + thr_bytes + coarse_bytes + 2u * cell_bytes);
   p.finemax = (const float*)(base + thr_bytes + coarse_bytes + 2u * cell_bytes + fine_bytes);
-  if (ahead)
+  if (ahead || two)
     p.ckpt = nullptr;
   else
   {
@@ -1915,9 +2045,9 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
     const uint32_t cell_blocks = (uint32_t)((p.cw * p.ch + 3) / 4);
     const uint32_t ckpt_blocks = p.ckpt ? (p.plane + 255u) / 256u : 0u;
     const uint32_t brick_blocks = (uint32_t)((p.ccw * p.cch + 3) / 4);
-    const uint32_t fine_blocks = (uint32_t)((p.fcw * p.fch + 255) / 256);
+    const uint32_t fine_blocks = two ? (uint32_t)((p.fcw * p.fch + 255) / 256) : 0u;  // (only the two-kernel launch looks at them)
     // (one more workgroup sums up the class bytes of the launch before this one: see prepass_kernel)
-    const uint32_t stats_blocks = !ahead && !use_static && ctx->classes && ctx->classes_n != 0 && ctx->stats_host ? 1u : 0u;
+    const uint32_t stats_blocks = !ahead && !use_static && slot == 0 && ctx->classes && ctx->classes_n != 0 && ctx->stats_host ? 1u : 0u;
     hipLaunchKernelGGL(prepass_kernel, dim3(thr_blocks + cell_blocks + brick_blocks + fine_blocks + stats_blocks + ckpt_blocks),
                        dim3(256), 0, ctx->stream, p.dists, p.dists_pitch, p.rows, p.cols, p.trunc_hi, (f32x2*)base,
                        (float*)(base + thr_bytes), p.cw, p.ch, bk, thr_blocks_x, thr_blocks, ckpt_blocks, p,
@@ -1930,6 +2060,7 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
   {
     ctx->prepared.dists = (const void*)p.dists, ctx->prepared.pitch = p.dists_pitch, ctx->prepared.rows = p.rows;
     ctx->prepared.cols = p.cols, ctx->prepared.trunc_hi = p.trunc_hi, ctx->prepared.slot = slot, ctx->prepared.valid = true;
+    ctx->prepared.fine = two;
     ctx->prepared_next = slot ^ 1;
     return 0;
   }
@@ -1941,14 +2072,8 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
   // z >= f * P * 2^-15 keeps that below a quarter of the margin.
   {
     const float margin = 1.f / 64.f;
-    float P = 0.f;
-    for (int i = 0; i < 3; ++i)
-    {
-      const float ext = fabsf(p.R[3 * i + 0]) * p.vsx * (float)p.X + fabsf(p.R[3 * i + 1]) * p.vsy * (float)p.Y +
-                        fabsf(p.R[3 * i + 2]) * p.vsz * (float)p.z1 + fabsf(p.t[i]);
-      P = fmaxf(P, ext);
-    }
-    const float f = fmaxf(fabsf(p.fx), fabsf(p.fy));
+    float P, f;
+    pose_extent(p, &P, &f);
     p.grp_margin = margin;
     p.grp_cols_hi = (float)p.cols - margin;
     p.grp_rows_hi = (float)p.rows - margin;
@@ -1963,42 +2088,28 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
     p.brick_eps = (float)(p.z1 + 32) * 0x1p-22f * P;
     p.brick_zmin = fmaxf(p.grp_zmin, 8.f * p.brick_eps);
     p.brick_stats = use_static ? nullptr : ctx->brick_stats;
-    p.brick_enable = ctx->brick_test && p.fx > 0.f && p.fy > 0.f && p.cols < 32768 && p.rows < 32768 &&
-                     std::isfinite(P) && std::isfinite(f) && std::isfinite(p.cx) && std::isfinite(p.cy);
+    p.brick_enable = brick_test_allowed(ctx, p);
   }
   return 0;
 }
 
-// Whether a launch goes through the two kernels (classify_kernel / integrate_list_kernel), and their memory: a class
-// byte per wave brick, padded with zeros to a multiple of 1024, and the column checkpoints.
+// The memory of the brick test's findings -- a class byte per wave brick, padded with zeros to a multiple of 1024 -- and,
+// for a launch in two kernels (p.two_kernels, decided by want_two_kernels), of the column checkpoints.
 static int prepare_list(yakhip_ctx* ctx, IntegrateParams& p, uint64_t wave_bricks, uint32_t blocks_x, int vx, bool use_static)
 {
   p.classes = nullptr;
   p.n_bricks = 0;
   p.grid_x = blocks_x;
   p.cptab = nullptr;
-  p.cp_stride = p.cp_count = 0;
-  p.two_kernels = 0;
-  // (the entry point that allocates nothing keeps to one kernel: the checkpoints alone are 50 MB for a 512^2 plane)
-  if (use_static || !ctx->defer_mixed || !p.brick_enable || vx != 4 || (ctx->defer_mixed == 1 && wave_bricks < kDeferMinWaves) ||
-      wave_bricks >= (1u << 28))
-    return 0;
-  // Which launch: the two kernels pay where mixed bricks are many and front bricks few (an orbit frame at 512^3:
-  // 0.109 -> 0.093 ms); a frame that is mostly free space streams best from the one-kernel grid (the wall scene:
-  // 0.182 against 0.25 ms).  The launcher goes by what the brick test found in an earlier frame of this volume --
-  // the previous launch's class bytes, summed up by this launch's prepass into pinned memory and read here without
-  // waiting, so it is two frames old or older -- and starts with one kernel.  Either way the voxels are the same.
-  // A caller that enqueues frame after frame without ever waiting gets one kernel, as before: the findings must be
-  // those of one of the last four launches to count (a frame loop that waits once per frame, as tracking does, sees
-  // the launch before the previous one).
-  bool two = ctx->defer_mixed == 2;
-  ctx->launch_seq += 1;
-  if (ctx->defer_mixed == 1 && ctx->stats_host)
+  p.cp_stride = p.cp_count = p.cp_ffwd = 0;
+  if (use_static || !ctx->defer_mixed || !p.brick_enable || vx != 4 || wave_bricks >= (1u << 28))
   {
-    const volatile uint32_t* st = ctx->stats_host;
-    const uint32_t front = st[0], mixed = st[1], n = st[2], seq = st[3];
-    two = n == wave_bricks && ctx->launch_seq - seq <= 4u && mixed >= 1024u && front <= 2u * mixed;
+    if (p.two_kernels)
+      return fail(YAKHIP_EINVAL, "integrate: a two-kernel launch was planned for a layout that has none");  // (cannot happen)
+    return 0;
   }
+  ctx->launch_seq += 1;
+  ctx->seq_signature[ctx->launch_seq & 7u] = volume_signature(p);
   const size_t bytes_cls = ((size_t)wave_bricks + 1023u) & ~(size_t)1023u;
   if (ctx->classes_bytes < bytes_cls)
   {
@@ -2021,9 +2132,8 @@ static int prepare_list(yakhip_ctx* ctx, IntegrateParams& p, uint64_t wave_brick
   p.classes = ctx->classes;
   p.n_bricks = (uint32_t)wave_bricks;
   ctx->classes_seq = ctx->launch_seq;  // (the launch these class bytes will be of)
-  if (!two)
+  if (!p.two_kernels)
     return 0;
-  p.two_kernels = 1;
   // column checkpoints every cp_stride layers, at most 256 MiB of them
   const int layers = p.z1 - p.z0;
   int stride = kCheckpointStride;
@@ -2046,6 +2156,7 @@ static int prepare_list(yakhip_ctx* ctx, IntegrateParams& p, uint64_t wave_brick
   p.cptab = ctx->cptab;
   p.cp_stride = stride;
   p.cp_count = count;
+  p.cp_ffwd = p.z0 >= kCheckpointFrom && ctx->checkpoint;  // (as a one-kernel launch of the slab would start: prepare_checkpoint)
   return 0;
 }
 
@@ -2078,7 +2189,7 @@ static int choose_chunk(const yakhip_ctx* ctx, const IntegrateParams& p, uint32_
     // replay stays below about 8 steps per layer of real work it hides behind the memory traffic (a whole
     // 512-layer volume in 32-layer chunks: 256 / 32); a slab deep inside a tall volume needs longer chunks
     // for that (measured, rank 7 of 8 at 1024^3, layers [896, 1024): 0.264 ms with 32-layer chunks).
-    const int for_replay = ((p.ckpt ? 0 : p.z0) + layers / 2) / (graded ? 12 : 8);  // (with a checkpoint the replay starts at z0)
+    const int for_replay = ((p.ckpt || p.two_kernels ? 0 : p.z0) + layers / 2) / (graded ? 12 : 8);  // (with a checkpoint the replay starts at z0)
     if (chunk < for_replay)
     {
       const int n = layers / for_replay > 1 ? layers / for_replay : 1;
@@ -2187,20 +2298,11 @@ static int choose_tile(const yakhip_ctx* ctx, const IntegrateParams& p, int vx)
 int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in, bool use_static)
 {
   IntegrateParams p = p_in;
-  const uintptr_t base = (uintptr_t)p.vol;
-  int rc = prepare_frame(ctx, p, 0, 1, 32768, use_static);
+  const int vx = widest_vector(ctx, p);
+  p.two_kernels = want_two_kernels(ctx, p, vx, use_static);
+  int rc = prepare_frame(ctx, p, 0, 1, 32768, use_static, false, p.two_kernels != 0);
   if (rc != 0)
     return rc;
-
-  // widest vector the layout allows: rows must not straddle a lane's group and the slab base,
-  // every row start and every layer start must be aligned to the vector size
-  int vx = 1;
-  if (p.X % 4 == 0 && base % 16 == 0)
-    vx = 4;
-  else if (p.X % 2 == 0 && base % 8 == 0)
-    vx = 2;
-  if (ctx->force_vx > 0 && ctx->force_vx < vx)
-    vx = ctx->force_vx;
 
   const uint32_t groups = p.plane / (uint32_t)vx;
   const uint32_t blocks_x = (groups + 255u) / 256u;
@@ -2247,9 +2349,10 @@ int launch_integrate(yakhip_ctx* ctx, const IntegrateParams& p_in, bool use_stat
 int launch_integrate_prepare(yakhip_ctx* ctx, const IntegrateParams& p_in)
 {
   IntegrateParams p = p_in;
-  if (p.z0 >= kCheckpointFrom && ctx->checkpoint)
-    return 0;  // a deep slab's prepass also computes its column checkpoints from the pose: nothing to do ahead of time
-  return prepare_frame(ctx, p, 0, 1, 32768, false, true);
+  const bool two = want_two_kernels(ctx, p, widest_vector(ctx, p), false, false);
+  if (!two && p.z0 >= kCheckpointFrom && ctx->checkpoint)
+    return 0;  // a deep slab's one-kernel prepass also computes its column checkpoints from the pose: nothing to do ahead of time
+  return prepare_frame(ctx, p, 0, 1, 32768, false, true, two);
 }
 
 // ---- multi-camera batched integrate ---------------------------------------------------------------
@@ -2297,6 +2400,9 @@ __global__ __launch_bounds__(256, 2) void integrate_batch_kernel(const BatchPara
   bool fill = p.grp_enable;
   if (p.brick_enable)
   {
+    if (p.classes && (threadIdx.x & 63u) == 0)  // what the first frame's test found: the launcher's findings (prepare_list)
+      p.classes[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6)] =
+          (uint8_t)(cls[0] == kBrickDead ? 0u : (cls[0] == kBrickFront ? 0x81u : 1u));
     if ((threadIdx.x & 63u) == 0)
       wave_mixed[threadIdx.x >> 6] = any_mixed;
     __syncthreads();
@@ -2464,11 +2570,32 @@ int launch_integrate_batch(yakhip_ctx* ctx, const IntegrateParams* frames, int n
       done += 1;
       continue;
     }
+    // A sweep of K frames pays 8 B per touched voxel once instead of K times -- where the frames are mostly free space.
+    // Where they are mostly surface (mixed bricks outnumbering front bricks two to one in a recent launch of this
+    // volume: recent_findings) the walk is bound by arithmetic, not by traffic, and K single-frame launches, each in two
+    // kernels, are faster (512^3 orbit: 0.094 against 0.146 ms per frame; a 2048 x 2048 x 256 slab of configuration 5,
+    // four cameras: 1.49 against 1.77 ms).  The voxels are the same either way, by definition of the sweep.
+    {
+      double front = 0, mixed = 0;
+      if (ctx->defer_mixed == 1 && (uint64_t)p0.plane * (uint64_t)(p0.z1 - p0.z0) >= (1ull << 25) &&
+          recent_findings(ctx, p0, &front, &mixed) && mixed >= 0.03 && front <= 0.5 * mixed)
+      {
+        for (int i = 0; i < k; ++i)
+        {
+          const int rc = launch_integrate(ctx, frames[done + i]);
+          if (rc != 0)
+            return rc;
+        }
+        done += k;
+        continue;
+      }
+    }
     BatchParams bp;
     const size_t coarse_cap = 32768 / (size_t)k;  // all K coarse images share the workgroup's LDS
     for (int i = 0; i < k; ++i)
     {
       bp.f[i] = frames[done + i];
+      bp.f[i].two_kernels = 0;  // (the sweep is one kernel)
       if (bp.f[i].rows != p0.rows || bp.f[i].cols != p0.cols)
         return fail(YAKHIP_EINVAL, "integrate_batch: frames must have the same image size");
       const int rc = prepare_frame(ctx, bp.f[i], i, k, coarse_cap);
@@ -2508,6 +2635,10 @@ int launch_integrate_batch(yakhip_ctx* ctx, const IntegrateParams* frames, int n
     const dim3 grid(blocks_x, chunk_table(ctx, bp.f[0], chunk, 16, &chunks));
     if (grid.y == 0)
       return fail(YAKHIP_ERANGE, "integrate: the volume needs more than %d z-chunks of at most 2 GiB", kMaxChunks);
+    // (the sweep leaves the first frame's brick classes behind, as every launch does: the findings above)
+    bp.f[0].two_kernels = 0;
+    if ((rc = prepare_list(ctx, bp.f[0], (uint64_t)grid.x * grid.y * 4u, grid.x, 4, false)) != 0)
+      return rc;
     const size_t lds = grp ? (size_t)k * bp.f[0].cw * bp.f[0].ch * sizeof(float) : 0;
     switch (k)
     {

@@ -44,6 +44,7 @@ struct yakhip_ctx
     float trunc_hi;
     int slot;
     bool valid;
+    bool fine;  // the fine cells were filled too (what a two-kernel launch needs)
   } prepared;
   int prepared_next;   // slot the next prepare call writes (0 / 1 in turn)
   void* ckpt;          // scratch: column positions at layer z0 of a deep slab (integrate.hip, checkpoint_kernel)
@@ -52,6 +53,7 @@ struct yakhip_ctx
   size_t classes_bytes;
   uint64_t classes_n;  // ... bricks of the last launch that used it (the bytes behind them are zero)
   unsigned long long launches_one, launches_two;  // yakhip_ctx_launch_counts
+  uint32_t seq_signature[8];  // which volume the last launches were of
   uint32_t launch_seq, classes_seq;  // launches that could have used it so far; the one whose classes it holds
   uint32_t* stats_host; // pinned: {front bricks, mixed bricks, wave bricks, launch number} of an earlier launch (integrate.hip, prepare_list)
   float* cptab;        // ... and the column checkpoints (IntegrateParams::cptab)
@@ -125,6 +127,7 @@ struct IntegrateParams
                          // integrate_list_kernel deals the live bricks' parts out evenly (integrate.hip)
   uint32_t n_bricks, grid_x;  // wave bricks of the launch; plane tiles (workgroups of the one-kernel grid per chunk)
   float* cptab;          // two kernels: camera-space positions of every column at the layers z0 + k * cp_stride, k < cp_count
+  int cp_ffwd;           // the table starts from closed-form positions at z0 (a deep slab) / from z0 replayed steps
   int cp_stride, cp_count;  // (plane floats of x, then y, then z per k), written by extra workgroups of the first kernel, so
                          // that the second starts a part from the checkpoint below it instead of replaying from layer 0
   uint32_t* bricks;      // nullptr, or the slab's surface map: one bit per 16^3 brick, bricks_x x bricks_y x bricks_z,
