@@ -273,12 +273,19 @@ __global__ __launch_bounds__(256) void prepass_kernel(const uint8_t* dists, uint
     // it gets there: a hint) to choose between the one-kernel and the two-kernel launch for a later frame.
     const uint32_t groups = (prev_bricks + 1023u) >> 10;
     uint32_t front = 0, live = 0;
-    for (uint32_t i = 0; i < groups; ++i)
+    for (uint32_t i0 = 0; i0 < groups; i0 += 8u)  // (eight loads in flight: this workgroup must not outlast the others)
     {
-      const uint32_t w = prev_classes[i * 256u + threadIdx.x];
-      front += (uint32_t)__builtin_popcount(w & 0x80808080u);
-      const uint32_t u = w & 0x07070707u;
-      live += (uint32_t)__builtin_popcount((u | (u >> 1) | (u >> 2)) & 0x01010101u);
+      uint32_t w[8];
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; ++k)
+        w[k] = i0 + k < groups ? prev_classes[(i0 + k) * 256u + threadIdx.x] : 0u;
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; ++k)
+      {
+        front += (uint32_t)__builtin_popcount(w[k] & 0x80808080u);
+        const uint32_t u = w[k] & 0x07070707u;
+        live += (uint32_t)__builtin_popcount((u | (u >> 1) | (u >> 2)) & 0x01010101u);
+      }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
