@@ -258,6 +258,102 @@ def kinfu_loop_row(ctx):
     return out
 
 
+SHARDED_LOOP_EDGE = 1024   # BASELINE config 4: the 1024^3 volume of the S2 orbit, z-slabs over the ranks
+SHARDED_LOOP_FRAMES = 60
+
+
+def kinfu_loop_sharded_row(ctx, torch, capi, synth, dist, world, rank, frames=SHARDED_LOOP_FRAMES, edge=SHARDED_LOOP_EDGE):
+    """BASELINE config 4: the tracking loop over a z-slab sharded volume, one rank per GPU (yak_amd/kinfu_sharded.py over
+    yakhip_icp_estimate_sharded / yakhip_raycast_sharded: 19 all-reduces of 33 floats, the ray cast's composite -- MIN
+    over the keys, SUM over the winners' payload, the settled pixels once more).  Fused frames per second of the
+    slowest rank, stream time per stage (maximum over the ranks), and the frame's collectives once more on their own:
+    the same buffers and counts, nothing else on the stream.  All ranks call this; rank 0 gets the row."""
+    from yak_amd.kinfu_sharded import ShardedKinFu
+
+    rows, cols, intr = synth.ROWS, synth.COLS, synth.INTR
+    dims, vs, tr = synth.volume_geometry(edge)
+    kf = ShardedKinFu(ctx, dist if world > 1 else None, dims, vs, tr, synth.MAX_WEIGHT, intr, rows, cols)
+    scene = [synth.scene_s2(f, noise_mm=1.0) for f in range(frames)]
+    depth = [torch.from_numpy(d.view(np.int16)).cuda() for d, _, _ in scene]
+
+    def c2v(R_v2c, t_v2c):
+        R = R_v2c.astype(np.float64).T
+        return R, -R @ t_v2c.astype(np.float64)
+
+    def run(collect):
+        kf.ctx.clear_volume(kf.desc)
+        kf.frame = 0
+        kf.stage_events = [] if collect else None
+        fused = 0
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for f in range(frames):
+            fused += bool(kf(depth[f], first_pose=c2v(scene[0][1], scene[0][2]) if f == 0 else None))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return time.perf_counter() - t0, fused
+
+    run(False)  # warm-up: allocations, first launches, the communicator's first collectives
+    elapsed, fused = run(True)
+    stage = {}
+    for name, e0, e1 in kf.stage_events:
+        stage.setdefault(name, []).append(e0.elapsed_time(e1))
+    stage_ms = {k: sum(v) / len(v) for k, v in stage.items()}
+    R_true, t_true = c2v(scene[frames - 1][1], scene[frames - 1][2])
+    err_mm = float(np.linalg.norm(kf.pose_t - t_true) * 1e3)
+
+    # the collectives of one frame on their own (what DESIGN.md 5 tabulates): 19 x 33 floats SUM, the keys MIN, the
+    # payload SUM (7 words per pixel), the settled pixels' list SUM (32 B x max(4096, pixels / 64) slots)
+    small = torch.zeros(64, dtype=torch.float32, device="cuda")
+    keys = torch.zeros(rows * cols, dtype=torch.int32, device="cuda")
+    payload = torch.zeros(rows * cols * 7, dtype=torch.int32, device="cuda")
+    slots = torch.zeros(8 * max(4096, rows * cols // 64), dtype=torch.int32, device="cuda")
+
+    def timed_coll(fn, reps=10):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def icp_sums():
+        for _ in range(19):
+            ctx.allreduce(kf.comm, small.data_ptr(), 33, capi.SUM_F32)
+
+    coll = {"icp_19_x_33_floats_ms": timed_coll(icp_sums),
+            "raycast_keys_min_ms": timed_coll(lambda: ctx.allreduce(kf.comm, keys.data_ptr(), rows * cols, capi.MIN_I32)),
+            "raycast_payload_sum_ms": timed_coll(lambda: ctx.allreduce(kf.comm, payload.data_ptr(), rows * cols * 7, capi.SUM_I32)),
+            "raycast_settled_sum_ms": timed_coll(lambda: ctx.allreduce(kf.comm, slots.data_ptr(), slots.numel(), capi.SUM_I32))}
+    vals = [elapsed, err_mm] + [stage_ms.get(k, 0.0) for k in ("preprocess", "icp", "integrate", "raycast")] + list(coll.values())
+    t = torch.tensor(vals, dtype=torch.float64, device="cpu" if dist is not None and world > 1 and dist.get_backend() == "gloo" else "cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    vals = [float(v) for v in t]
+    transport = "one rank: no exchange" if world == 1 else ("RCCL (ncclAllReduce on the context's stream)" if dist.get_backend() == "nccl"
+                                                                else "gloo through the host (a rehearsal: not the transport of a real run)")
+    out = {"workload": "BASELINE config 4: %d^3 volume in %d z-slabs (+ the ray cast's halo, integrated redundantly), the first %d frames "
+                       "of the S2 orbit (1 mm depth noise) tracked from depth alone; per frame: pre-processing (replicated), ICP over "
+                       "row bands with 19 all-reduces of 33 floats, integrate (no exchange), slab ray cast + composite"
+                       % (edge, world, frames),
+           "host": "Python over the C ABI (yak_amd/kinfu_sharded.py), one process per GPU", "transport": transport,
+           "frames": frames, "frames_fused": fused, "fused_frames_per_s": round(frames / vals[0], 1),
+           "position_error_last_frame_mm": round(vals[1], 2),
+           "stage_ms_slowest_rank": {k: round(v, 4) for k, v in zip(("preprocess", "icp", "integrate", "raycast"), vals[2:6])},
+           "collectives_of_a_frame_on_their_own_ms": {k: round(v, 4) for k, v in zip(coll.keys(), vals[6:])},
+           "held_layers_rank0": list(kf.held), "halo_layers": kf.halo}
+    out["collectives_of_a_frame_on_their_own_ms"]["sum"] = round(sum(vals[6:]), 4)
+    del kf, depth
+    torch.cuda.empty_cache()
+    return out if rank == 0 else None
+
+
 def cpp_loop_rates(frames):
     """The same orbit through the C++ classes (kfusion::KinFu in examples/offline_fuse, a child process): its frames
     come from host memory, so every frame's upload is inside the figure.  None if the example is not built."""
@@ -384,6 +480,16 @@ def c1_cpu_baseline(synth):
 
 
 def run_c5(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, emulate):
+    out = c5_measure(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, emulate)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def c5_measure(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, emulate, steps=None, warmup=None,
+               with_cpu=None):
     """One step = ONE SWEEP of the rank's 2048 x 2048 x 256 slab folding the K = 4 camera frames
     (yakhip_integrate_batch); marching cubes over the slab is timed beside it (it runs once per scan, not per
     sweep).  value = voxel updates of all ranks and all K frames per second of the slowest rank."""
@@ -411,6 +517,9 @@ def run_c5(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, e
         keep.append((d, dd, depth, R, t))
         frames.append((dd.data_ptr(), cols * 2, rows, cols, R.reshape(-1), t, intr))
     K = len(frames)
+    n_steps = args.steps if steps is None else steps
+    n_warm = args.warmup if warmup is None else warmup
+    with_cpu = (world == 1 and not args.no_cpu_baseline) if with_cpu is None else with_cpu
 
     def step():
         # one wait per sweep, as a rig that hands over K frames at a time has: the library chooses between one sweep
@@ -433,24 +542,24 @@ def run_c5(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, e
     touched = int((w != 0).sum().item())
     updates = int(w.sum(dtype=torch.int64).item())  # every update adds 1 to a weight (K < max_weight)
     touched_held = int(((vol >> 16) != 0).sum().item())
-    for _ in range(args.warmup):
+    for _ in range(n_warm):
         step()
     sync()
     ctx.kernel_time()  # (restarts the accumulation: what follows are the timed sweeps' launches only)
     counts0 = ctx.launch_counts()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(n_steps):
         step()
     sync()
     elapsed = time.perf_counter() - t0
     kernel_total_ms, kernel_launches = ctx.kernel_time()
     counts1 = ctx.launch_counts()
     ctx.set_option("kernel_timing", 0)
-    kernel_ms = kernel_total_ms / max(args.steps, 1)  # per sweep, whatever launches it was made of
+    kernel_ms = kernel_total_ms / max(n_steps, 1)  # per sweep, whatever launches it was made of
     single_launches = sum(counts1.values()) - sum(counts0.values())
     sweep_kernel = ("yakhip::integrate_batch_kernel<4, true>" if single_launches == 0 else
                     "%d x (yakhip::classify_kernel<4> + yakhip::integrate_list_kernel<4, true>)" % K
-                    if counts1["two_kernels"] - counts0["two_kernels"] == K * args.steps else "mixed: see launches_per_sweep")
+                    if counts1["two_kernels"] - counts0["two_kernels"] == K * n_steps else "mixed: see launches_per_sweep")
 
     # marching cubes over the slab (count, scan, emit), blocking calls
     ntri = ctx.marching_cubes(held, 2, vs[0])
@@ -488,12 +597,12 @@ def run_c5(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, e
         mc_bytes = 4 * visited + 36 * ntri  # the least any extraction moves: one read of the slab + the triangles
         out = {
             "metric": "voxel updates/sec",
-            "value": round(updates_total * args.steps / elapsed / 1e9, 3),
+            "value": round(updates_total * n_steps / elapsed / 1e9, 3),
             "unit": "Gvox/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "steps": n_steps,
+            "warmup": n_warm,
+            "ms_per_step": round(elapsed / n_steps * 1e3, 5),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -505,15 +614,15 @@ def run_c5(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, e
                                    % (n, n, C5_LAYERS_PER_RANK * world, n, vs[0] * 1e3, K, cols, rows),
                        "frames_per_step": K, "voxel_updates_per_step": updates_total, "voxels_touched_per_step": touched_total,
                        "voxels_visited_per_step": K * C5_LAYERS_PER_RANK * world * n * n, "voxel_bytes": 4,
-                       "visited_Gvox_per_s": round(K * C5_LAYERS_PER_RANK * world * n * n * args.steps / elapsed / 1e9, 1),
+                       "visited_Gvox_per_s": round(K * C5_LAYERS_PER_RANK * world * n * n * n_steps / elapsed / 1e9, 1),
                        "parallelism": "z-slab x%d" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": load_traffic("integrate_batch_c5_rank%d_of_%d" % (rank, world)),
                          "kernel": sweep_kernel, "kernel_ms": round(kernel_ms, 5),
-                         "launches_per_sweep": {"bracketed_kernel_launches": round(kernel_launches / max(args.steps, 1), 2),
-                                                "single_frame_calls_as_one_kernel": (counts1["one_kernel"] - counts0["one_kernel"]) / max(args.steps, 1),
-                                                "single_frame_calls_as_two_kernels": (counts1["two_kernels"] - counts0["two_kernels"]) / max(args.steps, 1)},
+                         "launches_per_sweep": {"bracketed_kernel_launches": round(kernel_launches / max(n_steps, 1), 2),
+                                                "single_frame_calls_as_one_kernel": (counts1["one_kernel"] - counts0["one_kernel"]) / max(n_steps, 1),
+                                                "single_frame_calls_as_two_kernels": (counts1["two_kernels"] - counts0["two_kernels"]) / max(n_steps, 1)},
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "rank %d's slab, kernel time per sweep of %d frames; bound by the per-voxel path of the bricks "
                                  "that hold surface, not by HBM (only touched voxels count as algorithmic bytes, once per "
@@ -532,7 +641,7 @@ def run_c5(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, e
         if emulate:
             out["config"]["emulated_rank"] = "%d of %d (this GPU's slab only: value is per GPU)" % (rank, world)
             out["n_gpus"] = 1
-        if world == 1 and not args.no_cpu_baseline:
+        if with_cpu:
             import oracle
 
             threads = min(oracle.max_threads(), os.cpu_count() or 1)
@@ -567,11 +676,12 @@ def run_c5(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, e
                           "linearly to the slab's %d layers (%.2f s per sweep)" % (
                               K, z0, z0 + 2, t2, r2, z0, z0 + 10, t10, r10, threads, C5_LAYERS_PER_RANK, t_slab)}
             out["marching_cubes"]["cpu_baseline"] = c1_cpu_baseline(synth)
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    else:
+        out = None
     ctx.close()
+    del vol, smap
+    torch.cuda.empty_cache()
+    return out
 
 
 def load_traffic(workload_key):
@@ -610,6 +720,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rows", action="store_true", help="skip the secondary measurements (raycast, ICP, MC, batch)")
     ap.add_argument("--as-rank", default="", metavar="W:R", help="diagnostic: time the slab of rank R of a W-GPU job on this one GPU")
+    ap.add_argument("--extra-rows", action="store_true", help="also with one rank: the rows an N > 1 run adds (config 5's sweep per rank, the sharded tracking loop of config 4)")
     ap.add_argument("--no-loop", action="store_true", help="skip the full KinFu loop row (its single-frame integrate launches would enter a kernel-trace average of the headline kernel)")
     args = ap.parse_args()
 
@@ -862,6 +973,25 @@ def main():
                     out["kinfu_loop"] = kinfu_loop_row(ctx)
                 except Exception as e:
                     out["kinfu_loop"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # N > 1: the same command also carries north_star's scaling targets: BASELINE config 5 -- each rank's
+    # 2048 x 2048 x 256 slab, four cameras per sweep, marching cubes -- and config 4, the sharded tracking loop.  All
+    # ranks take part; rank 0 adds the rows to its line.  (YAK_BENCH_EXTRA=0 leaves them out.)
+    extra = {}
+    if ((dist is not None and world > 1 and not emulate and not args.no_rows and os.environ.get("YAK_BENCH_EXTRA", "1") != "0") or
+            (args.extra_rows and not emulate)):
+        vol = None
+        torch.cuda.empty_cache()
+        for key, fn in (("c5", lambda: c5_measure(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, None,
+                                                  steps=min(args.steps, 10), warmup=min(args.warmup, 3), with_cpu=False)),
+                        ("kinfu_loop_sharded", lambda: kinfu_loop_sharded_row(ctx, torch, capi, synth, dist, world, rank))):
+            try:
+                extra[key] = fn()
+            except Exception as e:  # secondary: never take the headline down with it (every rank fails alike or hangs in a
+                extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}  # collective: the driver's time limit ends that)
+    if rank == 0 or emulate:
+        for k, v in extra.items():
+            if v is not None:
+                out[k] = v
         print(json.dumps(out), flush=True)
 
     if dist is not None:

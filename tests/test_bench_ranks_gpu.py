@@ -24,7 +24,7 @@ def test_two_ranks_through_torch_distributed_run():
     env = dict(os.environ, YAK_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                                   # rank 0 prints, once
@@ -36,6 +36,21 @@ def test_two_ranks_through_torch_distributed_run():
     # value = all ranks' voxels over the slowest rank's time
     assert abs(d["value"] - 2 * 512 ** 3 / (d["ms_per_step"] * 1e-3) / 1e9) < 0.01 * d["value"]
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    # the same command carries north_star's scaling targets: config 5's sweep per rank ...
+    c5 = d["c5"]
+    assert "error" not in c5, c5
+    assert c5["metric"] == "voxel updates/sec" and c5["n_gpus"] == 2 and c5["config"]["frames_per_step"] == 4
+    assert "2048x2048x512" in c5["config"]["workload"] and c5["value"] > 0 and c5["marching_cubes"]["triangles"] > 0
+    assert abs(c5["value"] - c5["config"]["voxel_updates_per_step"] / (c5["ms_per_step"] * 1e-3) / 1e9) < 0.01 * c5["value"]
+    # ... and config 4, the sharded tracking loop: frames per second, stage times, the frame's collectives on their own
+    lp = d["kinfu_loop_sharded"]
+    assert "error" not in lp, lp
+    assert "1024^3" in lp["workload"] and lp["frames"] == 60 and lp["frames_fused"] == 59 and lp["fused_frames_per_s"] > 1
+    assert set(lp["stage_ms_slowest_rank"]) == {"preprocess", "icp", "integrate", "raycast"}
+    assert all(v > 0 for v in lp["stage_ms_slowest_rank"].values())
+    assert set(lp["collectives_of_a_frame_on_their_own_ms"]) == {"icp_19_x_33_floats_ms", "raycast_keys_min_ms", "raycast_payload_sum_ms",
+                                                                  "raycast_settled_sum_ms", "sum"}
+    assert lp["position_error_last_frame_mm"] < 30.0 and "gloo" in lp["transport"]
 
 
 def test_one_rank_over_rccl():

@@ -70,6 +70,19 @@ class ShardedKinFu:
         self.first_R, self.first_t = np.eye(3), np.zeros(3)
         self.pose_R, self.pose_t = np.eye(3), np.zeros(3)          # camera -> volume
         self.frame = 0
+        self.stage_events = None  # measurement aid: a list to collect (stage, start event, end event) per call (bench.py)
+
+    def _stage(self, name, fn):
+        """Run one stage of the frame; with stage_events set, between two events on torch's current stream (the
+        context launches there)."""
+        if self.stage_events is None:
+            return fn()
+        e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.stage_events.append((name, e0, e1))
+        return r
 
     # ---- per-frame stages -------------------------------------------------------------------------
     def _preprocess(self, depth):
@@ -126,7 +139,7 @@ class ShardedKinFu:
         """depth: int16 (rows, cols) device tensor of millimetres.  pose = (R, t) camera -> volume to use
         instead of tracking (kinfu.cpp:228-253 with use_icp off); first_pose: where frame 0 is integrated.
         Returns True when the frame was fused (the reference reports false for frame 0, :191-201)."""
-        self._preprocess(depth)
+        self._stage("preprocess", lambda: self._preprocess(depth))
         if self.frame == 0:
             if first_pose is not None:
                 self.pose_R, self.pose_t = np.asarray(first_pose[0], dtype=np.float64), np.asarray(first_pose[1], dtype=np.float64)
@@ -139,7 +152,7 @@ class ShardedKinFu:
             self.frame += 1
             return False
         if pose is None:
-            ok, R, t = self._estimate_motion()
+            ok, R, t = self._stage("icp", self._estimate_motion)
             if not ok:
                 # kinfu.cpp:247-252: resetVolume() + resetPose() -- the volume is cleared, the frame counter goes
                 # to 0 and the next frame seeds the model again (every rank takes this branch alike)
@@ -151,8 +164,8 @@ class ShardedKinFu:
             self.pose_R, self.pose_t = self.pose_R @ R, self.pose_R @ t + self.pose_t     # kinfu.cpp:256-268
         else:
             self.pose_R, self.pose_t = np.asarray(pose[0], dtype=np.float64), np.asarray(pose[1], dtype=np.float64)
-        self._integrate()
-        self._raycast_model()
+        self._stage("integrate", self._integrate)
+        self._stage("raycast", self._raycast_model)
         self.ctx.synchronize()
         if self.world > 1 and self.ctx.comm_status(self.comm)[1]:
             # more pixels to settle than the composite's list holds (include/yakhip.h): once more with room for all
