@@ -34,7 +34,7 @@ ITERATIONS = (10, 5, 4)        # on levels 0, 1, 2 as ProjectiveICP::setIteratio
 class ShardedKinFu:
     def __init__(self, ctx, dist, dims, voxel_size, trunc_dist, max_weight, intr, rows, cols, device="cuda",
                  bilateral=(7, 4.5, 0.04), icp_dist_thres=0.1, icp_angle_thres=math.radians(30.0), step_factor=0.75,
-                 gradient_delta_factor=0.5, comm=None):
+                 gradient_delta_factor=0.5, comm=None, tsdf_min_camera_movement=0.0):
         import torch
 
         self.torch, self.ctx, self.dist = torch, ctx, dist
@@ -44,6 +44,8 @@ class ShardedKinFu:
         self.intr, self.rows, self.cols, self.device = tuple(intr), rows, cols, device
         self.bilateral, self.dist_thres, self.angle_thres = bilateral, icp_dist_thres, icp_angle_thres
         self.step_factor, self.gdf = step_factor, gradient_delta_factor
+        self.min_move = tsdf_min_camera_movement   # KinFuParams::tsdf_min_camera_movement (0: every frame is integrated)
+        self.integrated = False                    # whether the last call integrated its frame (the movement gate)
 
         self.own = slab_range(self.dims[2], self.world, self.rank)
         probe = capi.volume_desc(256, self.dims, self.vs, trunc_dist, max_weight)
@@ -98,14 +100,16 @@ class ShardedKinFu:
             ctx.compute_points_normals(li, self.cur_d[l].data_ptr(), (cols >> l) * 2, rows >> l, cols >> l,
                                        self.cur_p[l].data_ptr(), (cols >> l) * 16, self.cur_n[l].data_ptr(), (cols >> l) * 16)
 
-    def _estimate_motion(self):
+    def _estimate_motion(self, hint=None):
         """ProjectiveICP::estimateTransform, projective_icp.cpp:175-232, over the ranks: yakhip_icp_estimate_sharded
         runs the whole coarse-to-fine schedule on the device -- every rank its band of rows, the 33 sums of each
-        linearisation all-reduced on the stream -- and the host waits once.  Returns (ok, R, t): current ->
+        linearisation all-reduced on the stream -- and the host waits once.  hint (R, t): the motion the estimate
+        starts from (use_pose_hints, kinfu.cpp:213-219; identity otherwise).  Returns (ok, R, t): current ->
         previous camera, the same bits on every rank."""
         levels = [(self.cur_p[l].data_ptr(), self.cur_n[l].data_ptr(), self.prv_p[l].data_ptr(), self.prv_n[l].data_ptr(),
                    (self.cols >> l) * 16, self.rows >> l, self.cols >> l, ITERATIONS[l]) for l in range(LEVELS)]
-        R, t, ok = self.ctx.icp_estimate_sharded(self.comm, np.eye(3).reshape(-1), np.zeros(3), self.intr, self.dist_thres,
+        R0, t0 = (np.eye(3), np.zeros(3)) if hint is None else hint
+        R, t, ok = self.ctx.icp_estimate_sharded(self.comm, np.float32(R0).reshape(-1), np.float32(t0), self.intr, self.dist_thres,
                                                  self.angle_thres, levels)
         return ok, np.float64(R).reshape(3, 3), np.float64(t)
 
@@ -135,16 +139,20 @@ class ShardedKinFu:
                                       (cols >> l) * 16, self.prv_n[l].data_ptr(), (cols >> l) * 16)
 
     # ---- the loop body ----------------------------------------------------------------------------
-    def __call__(self, depth, pose=None, first_pose=None):
+    def __call__(self, depth, pose=None, first_pose=None, motion_hint=None):
         """depth: int16 (rows, cols) device tensor of millimetres.  pose = (R, t) camera -> volume to use
-        instead of tracking (kinfu.cpp:228-253 with use_icp off); first_pose: where frame 0 is integrated.
+        instead of tracking (kinfu.cpp:228-253 with use_icp off); first_pose: where frame 0 is integrated;
+        motion_hint (R, t): inputCameraMotion with use_pose_hints (current -> previous camera) -- where the ICP
+        starts, and what the movement gate looks at (kinfu.cpp:279-285: the hint, not the corrected motion).
         Returns True when the frame was fused (the reference reports false for frame 0, :191-201)."""
         self._stage("preprocess", lambda: self._preprocess(depth))
+        self.integrated = False
         if self.frame == 0:
             if first_pose is not None:
                 self.pose_R, self.pose_t = np.asarray(first_pose[0], dtype=np.float64), np.asarray(first_pose[1], dtype=np.float64)
                 self.first_R, self.first_t = self.pose_R.copy(), self.pose_t.copy()
             self._integrate()
+            self.integrated = True
             # kinfu.cpp:196-198 swaps the frame's own maps in as the first model maps
             self.cur_p, self.prv_p = self.prv_p, self.cur_p
             self.cur_n, self.prv_n = self.prv_n, self.cur_n
@@ -152,7 +160,7 @@ class ShardedKinFu:
             self.frame += 1
             return False
         if pose is None:
-            ok, R, t = self._stage("icp", self._estimate_motion)
+            ok, R, t = self._stage("icp", lambda: self._estimate_motion(motion_hint))
             if not ok:
                 # kinfu.cpp:247-252: resetVolume() + resetPose() -- the volume is cleared, the frame counter goes
                 # to 0 and the next frame seeds the model again (every rank takes this branch alike)
@@ -164,7 +172,13 @@ class ShardedKinFu:
             self.pose_R, self.pose_t = self.pose_R @ R, self.pose_R @ t + self.pose_t     # kinfu.cpp:256-268
         else:
             self.pose_R, self.pose_t = np.asarray(pose[0], dtype=np.float64), np.asarray(pose[1], dtype=np.float64)
-        self._stage("integrate", self._integrate)
+        # kinfu.cpp:279-290: no integration if the camera (by the hint) did not move
+        hint_R, hint_t = (np.eye(3), np.zeros(3)) if motion_hint is None else motion_hint
+        rnorm = np.float32(math.acos(min(1.0, max(-1.0, (np.trace(np.float64(hint_R)) - 1.0) / 2.0))))
+        tnorm = np.float32(np.linalg.norm(np.float64(hint_t)))
+        if (rnorm + tnorm) / 2 >= self.min_move:
+            self._stage("integrate", self._integrate)
+            self.integrated = True
         self._stage("raycast", self._raycast_model)
         self.ctx.synchronize()
         if self.world > 1 and self.ctx.comm_status(self.comm)[1]:
