@@ -66,6 +66,9 @@ public:
   }
   bool empty() const;
   size_t sizeBytes() const;
+  /** True if somebody else can reach this storage too: another DeviceMemory aliases it, or it wraps user memory.
+   *  No counterpart in the reference (its counter is private, device_memory.hpp:93). */
+  bool shared() const;
 
 private:
   void* data_;

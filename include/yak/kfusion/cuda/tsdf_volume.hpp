@@ -91,13 +91,13 @@ public:
   };
 
 private:
-  bool ensureSlab();  // (re)allocates (and clears) the held layers when the sharding or the halo-relevant parameters changed
+  bool ensureSlab();  // (re)allocates the held layers when the sharding or the halo-relevant parameters changed; a fused model is carried over
   yakhip_volume view() const;  // the held layers as the C ABI takes them
   void freshSurfaceMap();      // recompute the surface map if voxels may have been written behind the class's back
 
   int held_z0_, held_z1_;          // layers in data_ (0, dims[2] on one GPU)
   bool blocking_integrate_;
-  bool map_stale_;                 // data() / swap() handed the voxels out since the map was last known good
+  bool map_stale_;                 // data() / swap() handed the voxels out and a handle may still be alive: consults rebuild the map
   CudaData surface_map_;           // one bit per 16^3 brick of the held layers (include/yakhip.h: yakhip_volume.surface_map)
   DeviceArray2D<int> keys_;        // sharded ray cast: the march-ending pair of every pixel
   CudaData data_;

@@ -56,6 +56,7 @@ public:
 private:
   struct Rank;
   void worker(Rank* r);
+  std::string waitAll(bool abort_peers);
   void shutdown();
 
   KinFuParams params_;

@@ -37,6 +37,7 @@ extern "C" {
 #define YAKHIP_EALIGN (-2)   /* pointer / pitch not aligned as required */
 #define YAKHIP_ENOGPU (-3)   /* no usable HIP device */
 #define YAKHIP_ERANGE (-4)   /* value outside what the kernels support (e.g. max_weight > 32767) */
+#define YAKHIP_EABORTED (-5) /* the communicator was aborted, or a rank of its group left (yakhip_comm_abort) */
 
 typedef struct yakhip_ctx yakhip_ctx;
 
@@ -352,6 +353,14 @@ int yakhip_comm_create_local(int world, yakhip_comm** comms_out);
 typedef int (*yakhip_allreduce_fn)(void* user, void* buf_dev, size_t count, int op, void* hip_stream);
 int yakhip_comm_create_custom(yakhip_comm** out, int world, int rank, yakhip_allreduce_fn fn, void* user);
 int yakhip_comm_destroy(yakhip_comm* comm);
+/* The failure path (no counterpart in the reference: one GPU, no peers).  A rank that cannot go on aborts its
+ * communicator instead of leaving its peers waiting: local transport -- every rank waiting in an exchange of the
+ * group returns YAKHIP_EABORTED; RCCL -- ncclCommAbort: the collectives of THIS communicator that are in flight stop
+ * waiting for their peers and its stream drains (results undefined).  May be called from any thread, also while
+ * another thread is inside a collective on the communicator (that is the point: the thread that dispatched the
+ * frame aborts the communicators of the ranks still blocked on the one that failed).  Afterwards every collective on
+ * the communicator returns YAKHIP_EABORTED; yakhip_comm_destroy is the only call left.  Idempotent. */
+int yakhip_comm_abort(yakhip_comm* comm);
 int yakhip_comm_info(const yakhip_comm* comm, int* rank, int* world);
 /* In-place all-reduce of `count` 4-byte values in device memory, ordered on the context's stream. */
 int yakhip_comm_allreduce(yakhip_ctx* ctx, yakhip_comm* comm, void* buf_dev, size_t count, int op);

@@ -7,6 +7,7 @@
 #include <yak/yak_server.h>
 
 #include <yak_oracle.h>
+#include <yakhip.h>
 
 #include "../../yak_amd/csrc/solve6.hpp"
 
@@ -568,6 +569,178 @@ static void test_sharded_kinfu_against_single()
   EXPECT(kfusion::ShardedKinFu::devicesFromEnvironment().empty() || std::getenv("YAK_HIP_DEVICES"));
 }
 
+
+// A rank that throws mid-frame must not leave its peers waiting in an exchange for ever:
+// the worker aborts its communicator, the dispatching thread aborts the peers', everybody comes back with an error.
+static void test_sharded_failure_wakes_peers()
+{
+  std::printf("ShardedKinFu: a rank that throws wakes the ranks waiting for it\n");
+  kfusion::KinFuParams p = kfusion::KinFuParams::default_params();
+  p.volume_dims = kfusion::Vec3i::all(64);
+  p.volume_resolution = 3.f / 64.f;
+  kfusion::ShardedKinFu sharded(p, std::vector<int>{ 0, 0, 0 });
+  auto exchange = [](int rank) {
+    const kfusion::cuda::Shard& sh = kfusion::cuda::currentShard();
+    kfusion::cuda::DeviceArray<int> buf(4);
+    const int ones[4] = { 1, 1, 1, 1 };
+    buf.upload(ones, 4);
+    if (yakhip_comm_allreduce(kfusion::cuda::context(), sh.comm, buf.ptr(), 4, YAKHIP_SUM_I32) != 0)
+      throw std::runtime_error(yakhip_last_error());
+    int got[4] = { 0, 0, 0, 0 };
+    buf.download(got);
+    if (got[0] != sh.world || got[3] != sh.world)
+      throw std::runtime_error("rank " + std::to_string(rank) + ": wrong sum");
+  };
+  bool ok = true;
+  try
+  {
+    sharded.forEachRank([&](int rank, kfusion::KinFu&) { exchange(rank); });  // all three: works
+  }
+  catch (const std::exception& e)
+  {
+    std::printf("  unexpected: %s\n", e.what());
+    ok = false;
+  }
+  EXPECT(ok);
+  std::string what;
+  try
+  {
+    sharded.forEachRank([&](int rank, kfusion::KinFu&) {
+      if (rank == 1)
+        throw std::runtime_error("rank 1 gives up");
+      exchange(rank);  // ranks 0 and 2 wait for rank 1, which never comes
+    });
+  }
+  catch (const std::exception& e)
+  {
+    what = e.what();
+  }
+  std::printf("  forEachRank threw: %s\n", what.c_str());
+  EXPECT(what.find("rank 1 gives up") != std::string::npos);  // the cause, not a peer's "left the group"
+  // the communicators are dead: the next exchange fails at once on every rank instead of hanging
+  what.clear();
+  try
+  {
+    sharded.forEachRank([&](int rank, kfusion::KinFu&) { exchange(rank); });
+  }
+  catch (const std::exception& e)
+  {
+    what = e.what();
+  }
+  EXPECT(what.find("abort") != std::string::npos || what.find("left the group") != std::string::npos);
+}  // (and the destructor joins the workers)
+
+// The halo of a rank's slab follows trunc_dist / voxel size / the ray-cast factors; changing one of them after frames
+// have been fused keeps the fused model (the reference's setters never touch the voxels, tsdf_volume.cpp:54-78).
+static void test_slab_range_change_keeps_model()
+{
+  std::printf("ShardedKinFu: a setter that moves the halo keeps the fused model\n");
+  kfusion::KinFuParams p = kfusion::KinFuParams::default_params();
+  p.volume_dims = kfusion::Vec3i::all(96);
+  p.volume_resolution = 3.f / 96.f;
+  p.volume_pose = orbit_pose(0);
+  p.use_icp = false;
+  p.update_via_sensor_motion = false;
+  const size_t voxels = (size_t)96 * 96 * 96;
+  kfusion::KinFu single(p);
+  kfusion::ShardedKinFu sharded(p, std::vector<int>{ 0, 0, 0 });
+  auto frame = [&](int f) {
+    const Affine3f pose = orbit_pose(3 * f), prev = orbit_pose(f ? 3 * (f - 1) : 0);
+    std::vector<std::uint16_t> depth = render_s2(pose, p.intr, p.rows, p.cols);
+    kfusion::cuda::Depth d;
+    d.upload(depth.data(), (size_t)p.cols * 2, p.rows, p.cols);
+    single(Affine3f::Identity(), pose, prev, d);
+    sharded(Affine3f::Identity(), pose, prev, depth.data(), (size_t)p.cols * 2, p.rows, p.cols);
+  };
+  std::vector<std::uint32_t> one(voxels), many(voxels);
+  auto same_volume = [&]() {
+    single.tsdf().data().download(one.data());
+    std::fill(many.begin(), many.end(), 0xdeadbeefu);
+    sharded.downloadVolume(many.data());
+    size_t nonzero = 0;
+    for (size_t i = 0; i < voxels; ++i)
+      nonzero += one[i] != 0;
+    return nonzero > voxels / 20 && std::memcmp(one.data(), many.data(), voxels * 4) == 0;
+  };
+  for (int f = 0; f < 3; ++f)
+    frame(f);
+  EXPECT(same_volume());
+  std::vector<int> held_before(6), held_after(6);
+  auto held = [&](std::vector<int>& out) {
+    sharded.forEachRank([&](int rank, kfusion::KinFu& kf) { kf.tsdf().heldLayers(out[2 * rank], out[2 * rank + 1]); });
+  };
+  held(held_before);
+  const float factors[2] = { 4.f, 0.25f };  // the halo grows, then shrinks below where it began
+  for (float factor : factors)
+  {
+    single.tsdf().setGradientDeltaFactor(factor);
+    sharded.forEachRank([&](int, kfusion::KinFu& kf) { kf.tsdf().setGradientDeltaFactor(factor); });
+    held(held_after);
+    EXPECT(held_after != held_before);
+    held_before = held_after;
+    frame(3 + (factor < 1.f));  // the next frame reallocates the slab: the model so far must come along
+    EXPECT(same_volume());
+  }
+}
+
+// TsdfVolume::data() hands out a handle that aliases the voxels; writes through it after a ray cast has already
+// rebuilt the surface map must still be seen by the next ray cast (staleness is sticky while a handle lives).
+static void test_writable_handle_keeps_map_honest()
+{
+  std::printf("TsdfVolume::data(): writes through a kept handle after a ray cast\n");
+  kfusion::KinFuParams p = kfusion::KinFuParams::default_params();
+  p.volume_dims = kfusion::Vec3i::all(96);
+  p.volume_resolution = 3.f / 96.f;
+  p.volume_pose = orbit_pose(0);
+  p.use_icp = false;
+  p.update_via_sensor_motion = false;
+  const size_t voxels = (size_t)96 * 96 * 96;
+  const int rows = p.rows, cols = p.cols;
+  kfusion::KinFu full(p), sparse(p);
+  for (int f = 0; f < 4; ++f)
+  {
+    const Affine3f pose = orbit_pose(3 * f);
+    std::vector<std::uint16_t> depth = render_s2(pose, p.intr, rows, cols);
+    kfusion::cuda::Depth d;
+    d.upload(depth.data(), (size_t)cols * 2, rows, cols);
+    full(Affine3f::Identity(), pose, pose, d);
+    if (f == 0)
+    {
+      for (int y = 0; y < rows; ++y)  // `sparse` sees the left third of one frame only: few surface bricks
+        for (int x = cols / 3; x < cols; ++x)
+          depth[(size_t)y * cols + x] = 0;
+      d.upload(depth.data(), (size_t)cols * 2, rows, cols);
+      sparse(Affine3f::Identity(), pose, pose, d);
+    }
+  }
+  std::vector<std::uint32_t> model(voxels);
+  { const kfusion::cuda::TsdfVolume& cv = full.tsdf(); cv.data().download(model.data()); }
+  const Affine3f view = orbit_pose(4);
+  auto cast = [&](kfusion::cuda::TsdfVolume& vol, std::vector<float>& hp, std::vector<float>& hn) {
+    kfusion::cuda::Cloud points(rows, cols);
+    kfusion::cuda::Normals normals(rows, cols);
+    vol.raycast(view, p.intr, points, normals);
+    hp.resize((size_t)rows * cols * 4), hn.resize(hp.size());
+    points.download(hp.data(), (size_t)cols * 16);
+    normals.download(hn.data(), (size_t)cols * 16);
+  };
+  std::vector<float> want_p, want_n, got_p, got_n;
+  cast(full.tsdf(), want_p, want_n);
+  kfusion::cuda::CudaData handle = sparse.tsdf().data();  // writable, kept
+  cast(sparse.tsdf(), got_p, got_n);                      // rebuilds the map of the sparse model
+  size_t lit_sparse = 0, lit_full = 0;
+  for (size_t i = 0; i < (size_t)rows * cols; ++i)
+    lit_sparse += got_p[4 * i] == got_p[4 * i], lit_full += want_p[4 * i] == want_p[4 * i];
+  EXPECT(lit_sparse * 2 < lit_full);
+  handle.upload(model.data(), voxels * 4);                // the full model arrives behind the class's back
+  cast(sparse.tsdf(), got_p, got_n);
+  EXPECT(std::memcmp(got_p.data(), want_p.data(), want_p.size() * 4) == 0);
+  EXPECT(std::memcmp(got_n.data(), want_n.data(), want_n.size() * 4) == 0);
+  handle.release();                                        // no outside handle left: one last rebuild, then the map is trusted
+  cast(sparse.tsdf(), got_p, got_n);
+  EXPECT(std::memcmp(got_p.data(), want_p.data(), want_p.size() * 4) == 0);
+}
+
 // yak::FusionServer spread over ranks by YAK_HIP_DEVICES: fuse / downloadTSDF / reset / uploadTSDF / display
 // give what the one-GPU server gives (the volume word for word: supplied poses).
 static void test_fusion_server_over_ranks()
@@ -869,6 +1042,8 @@ int main(int argc, char** argv)
     {
       test_sharded_kinfu_against_single();
       test_fusion_server_over_ranks();
+      test_sharded_failure_wakes_peers();
+      test_slab_range_change_keeps_model();
     }
     else
     {
@@ -879,6 +1054,7 @@ int main(int argc, char** argv)
       test_marching_cubes_dipyramid();
       test_cloud_and_normals_against_oracle();
       test_render_views_against_oracle();
+      test_writable_handle_keeps_map_honest();
     }
   }
   catch (const std::exception& e)

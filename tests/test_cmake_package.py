@@ -17,6 +17,11 @@ def test_find_package_yak_consumer_builds_and_runs(tmp_path):
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "find_package(yak) consumer built and ran" in r.stdout
+    # the package build runs the store-data hazard gate on its own assembly of integrate.hip, as make does
+    assert "store-data hazard gate ran" in r.stdout and "0 problem(s)" in r.stdout
+    assert (tmp_path / "pkg" / "build" / "integrate.hazard-checked").exists()
+    cm = open(os.path.join(ROOT, "CMakeLists.txt")).read()
+    assert "add_dependencies(yakhip yakhip_hazard_check)" in cm
     prefix = tmp_path / "pkg" / "prefix"
     for f in ("lib/libyak.so", "lib/libyak_frontend.so", "lib/libyak_marching_cubes.so", "lib/libyakhip.so",
               "lib/cmake/yak/yak-config.cmake", "lib/cmake/yak/yak-targets.cmake", "include/yak/yak_server.h", "include/yakhip.h"):

@@ -311,3 +311,89 @@ def test_custom_transport(gpu_ctx):
         th.join(timeout=60)
     assert not errors, errors
     assert all(np.array_equal(r, np.full(33, 3.0, dtype=np.float32)) for r in results)
+
+
+# ---- the failure path: yakhip_comm_abort ------------------------------------
+def test_abort_wakes_a_rank_waiting_in_the_local_transport():
+    """Rank 0 sits in an all-reduce that rank 1 never joins; rank 1 aborts its communicator instead: rank 0 comes
+    back with YAKHIP_EABORTED, and every later exchange on either communicator fails at once."""
+    comms = capi.Comm.local(2)
+    ctx = capi.Context(0, use_torch_stream=False)
+    buf = torch.ones(16, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    seen = {}
+
+    def waiter():
+        try:
+            ctx.allreduce(comms[0], buf.data_ptr(), buf.numel(), capi.SUM_I32)
+            seen["rc"] = 0
+        except capi.YakHipError as e:
+            seen["rc"], seen["text"] = e.code, str(e)
+
+    th = threading.Thread(target=waiter)
+    th.start()
+    th.join(timeout=0.5)
+    assert th.is_alive()  # it waits for rank 1
+    comms[1].abort()
+    th.join(timeout=30)
+    assert not th.is_alive(), "the waiting rank was not woken"
+    assert seen["rc"] == capi.EABORTED and "left the group" in seen["text"]
+    comms[1].abort()  # idempotent
+    for c in comms:
+        with pytest.raises(capi.YakHipError) as e:
+            ctx.allreduce(c, buf.data_ptr(), buf.numel(), capi.SUM_I32)
+        assert e.value.code == capi.EABORTED
+    for c in comms:
+        c.close()
+    ctx.close()
+
+
+def test_completed_exchange_survives_a_peer_leaving():
+    """A rank that leaves (destroy) right after the last barrier of an exchange must not turn the exchange its slower
+    peer has completed into an error: many short exchanges, each followed by an immediate close on one side."""
+    for _ in range(40):
+        comms = capi.Comm.local(2)
+        out = [None, None]
+
+        def work(rank):
+            ctx = capi.Context(0, use_torch_stream=False)
+            b = torch.full((8,), rank + 1, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            try:
+                ctx.allreduce(comms[rank], b.data_ptr(), b.numel(), capi.SUM_I32)
+                ctx.synchronize()
+                out[rank] = b.cpu().numpy()
+            except capi.YakHipError as e:
+                out[rank] = e
+            if rank == 0:
+                comms[0].close()  # at once
+            ctx.close()
+
+        ths = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join(timeout=60)
+        comms[1].close()
+        for o in out:
+            assert isinstance(o, np.ndarray) and (o == 3).all(), o
+
+
+def test_rccl_abort_world_of_one(gpu_ctx):
+    """ncclCommAbort through the lazily opened librccl: afterwards collectives fail, destroy frees what is left."""
+    comm = capi.Comm.rccl(gpu_ctx, capi.Comm.unique_id(), 1, 0)
+    buf = torch.arange(32, dtype=torch.int32, device="cuda")
+    gpu_ctx.allreduce(comm, buf.data_ptr(), buf.numel(), capi.SUM_I32)
+    gpu_ctx.synchronize()
+    assert buf.cpu().tolist() == list(range(32))
+    comm.abort()
+    with pytest.raises(capi.YakHipError) as e:
+        gpu_ctx.allreduce(comm, buf.data_ptr(), buf.numel(), capi.SUM_I32)
+    assert e.value.code == capi.EABORTED and "aborted" in str(e.value)
+    comm.abort()
+    comm.close()
+    # the library is still usable: a fresh communicator works
+    again = capi.Comm.rccl(gpu_ctx, capi.Comm.unique_id(), 1, 0)
+    gpu_ctx.allreduce(again, buf.data_ptr(), buf.numel(), capi.SUM_I32)
+    gpu_ctx.synchronize()
+    again.close()

@@ -24,11 +24,12 @@ EXPORTS = [
     "yakhip_marching_cubes", "yakhip_marching_cubes_layers", "yakhip_weld_vertices", "yakhip_extract_cloud", "yakhip_extract_normals",
     "yakhip_render_image_points", "yakhip_render_image_depth", "yakhip_render_tangent_colors",
     "yakhip_comm_unique_id", "yakhip_comm_create_rccl", "yakhip_comm_create_local", "yakhip_comm_create_custom",
-    "yakhip_comm_destroy", "yakhip_comm_info", "yakhip_comm_allreduce", "yakhip_comm_status",
+    "yakhip_comm_destroy", "yakhip_comm_abort", "yakhip_comm_info", "yakhip_comm_allreduce", "yakhip_comm_status",
     "yakhip_raycast_sharded", "yakhip_icp_estimate_sharded",
 ]
 
 SUM_F32, MIN_I32, SUM_I32 = 0, 1, 2
+EINVAL, EALIGN, ENOGPU, ERANGE, EABORTED = -1, -2, -3, -4, -5  # include/yakhip.h
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 
 
@@ -154,6 +155,7 @@ def load():
         "yakhip_comm_create_local": [i, C.POINTER(vp)],
         "yakhip_comm_create_custom": [C.POINTER(vp), i, i, ALLREDUCE_FN, vp],
         "yakhip_comm_destroy": [vp],
+        "yakhip_comm_abort": [vp],
         "yakhip_comm_info": [vp, C.POINTER(i), C.POINTER(i)],
         "yakhip_comm_allreduce": [vp, vp, vp, sz, i],
         "yakhip_comm_status": [vp, vp, C.POINTER(C.c_uint)],
@@ -551,6 +553,10 @@ class Comm:
         r, w = C.c_int(0), C.c_int(0)
         _chk(load().yakhip_comm_info(self._h, C.byref(r), C.byref(w)))
         return r.value, w.value
+
+    def abort(self):
+        """yakhip_comm_abort: peers waiting on this rank return an error; every later collective here fails."""
+        _chk(load().yakhip_comm_abort(self._h))
 
     def close(self):
         if self._h is not None and self._h.value:

@@ -17,6 +17,7 @@
 #include <string.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -36,6 +37,7 @@ struct Rccl
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -56,9 +58,10 @@ int rccl(Rccl** out)
     lib.GetUniqueId = (decltype(lib.GetUniqueId))dlsym(lib.handle, "ncclGetUniqueId");
     lib.CommInitRank = (decltype(lib.CommInitRank))dlsym(lib.handle, "ncclCommInitRank");
     lib.CommDestroy = (decltype(lib.CommDestroy))dlsym(lib.handle, "ncclCommDestroy");
+    lib.CommAbort = (decltype(lib.CommAbort))dlsym(lib.handle, "ncclCommAbort");
     lib.AllReduce = (decltype(lib.AllReduce))dlsym(lib.handle, "ncclAllReduce");
     lib.GetErrorString = (decltype(lib.GetErrorString))dlsym(lib.handle, "ncclGetErrorString");
-    if (!lib.GetUniqueId || !lib.CommInitRank || !lib.CommDestroy || !lib.AllReduce || !lib.GetErrorString)
+    if (!lib.GetUniqueId || !lib.CommInitRank || !lib.CommDestroy || !lib.CommAbort || !lib.AllReduce || !lib.GetErrorString)
     {
       dlclose(lib.handle);
       lib.handle = nullptr;
@@ -86,19 +89,30 @@ struct LocalGroup
   std::vector<std::vector<uint32_t>> stage;  // one host vector per rank
   bool broken = false;
 
+  // true when every rank arrived.  A barrier that completed stays completed: a peer that has gone on to leave the
+  // group (destroy or abort set `broken`) before this rank woke up does not turn its finished exchange into an error.
   bool barrier()
   {
     std::unique_lock<std::mutex> lock(m);
+    if (broken)
+      return false;
     const unsigned long long g = generation;
     if (++arrived == world)
     {
       arrived = 0;
       ++generation;
       cv.notify_all();
+      return true;
     }
-    else
-      cv.wait(lock, [&] { return generation != g || broken; });
-    return !broken;
+    cv.wait(lock, [&] { return generation != g || broken; });
+    return generation != g;
+  }
+
+  void leave()
+  {
+    std::lock_guard<std::mutex> lock(m);
+    broken = true;  // ranks waiting in a barrier that can no longer complete give up instead of hanging
+    cv.notify_all();
   }
 };
 }  // namespace
@@ -115,12 +129,15 @@ struct yakhip_comm
   // device scratch of the ray-cast composite (allocated on first use, owned by the communicator)
   void* scratch;
   size_t scratch_bytes;
+  std::atomic<bool> aborted;  // yakhip_comm_abort ran: every later collective fails, destroy frees what is left
 };
 
 namespace yakhip
 {
 int comm_allreduce(yakhip_ctx* ctx, yakhip_comm* comm, void* buf, size_t count, int op)
 {
+  if (comm->aborted.load())
+    return fail(YAKHIP_EABORTED, "communicator of rank %d was aborted", comm->rank);
   if (comm->world == 1 && comm->kind != 0)
     return 0;
   if (comm->kind == 0)
@@ -145,7 +162,7 @@ int comm_allreduce(yakhip_ctx* ctx, yakhip_comm* comm, void* buf, size_t count, 
   YAKHIP_TRY(hipMemcpyAsync(mine.data(), buf, count * 4u, hipMemcpyDeviceToHost, ctx->stream));
   YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
   if (!g.barrier())
-    return fail(YAKHIP_EINVAL, "local communicator: a rank left the group");
+    return fail(YAKHIP_EABORTED, "local communicator: a rank left the group");
   std::vector<uint32_t> out(count);
   for (size_t i = 0; i < count; ++i)
   {
@@ -176,7 +193,7 @@ int comm_allreduce(yakhip_ctx* ctx, yakhip_comm* comm, void* buf, size_t count, 
     }
   }
   if (!g.barrier())  // everybody has read every stage vector: they may be overwritten by the next call
-    return fail(YAKHIP_EINVAL, "local communicator: a rank left the group");
+    return fail(YAKHIP_EABORTED, "local communicator: a rank left the group");
   YAKHIP_TRY(hipMemcpyAsync(buf, out.data(), count * 4u, hipMemcpyHostToDevice, ctx->stream));
   return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
 }
@@ -448,6 +465,7 @@ static yakhip_comm* new_comm(int kind, int rank, int world)
   yakhip_comm* c = new yakhip_comm();
   c->kind = kind, c->rank = rank, c->world = world;
   c->nccl = nullptr, c->fn = nullptr, c->user = nullptr, c->scratch = nullptr, c->scratch_bytes = 0;
+  c->aborted.store(false);
   return c;
 }
 
@@ -497,6 +515,30 @@ int yakhip_comm_create_custom(yakhip_comm** out, int world, int rank, yakhip_all
   return 0;
 }
 
+// The failure path: a rank that cannot go on (an exception mid-frame) aborts its communicator so that its peers do
+// not wait for it for ever.  Local transport: the group is marked broken and every rank waiting in a barrier
+// returns YAKHIP_EABORTED.  RCCL: ncclCommAbort ends the collectives of THIS communicator that are in flight (its
+// kernels stop polling for the missing peer and the stream drains); peers blocked on the rank that failed are
+// released by aborting THEIR communicators too, which any thread may do (ShardedKinFu::forEachRank does it from the
+// thread that dispatched the frame).  After an abort every collective on the communicator fails; destroy it.
+int yakhip_comm_abort(yakhip_comm* comm)
+{
+  if (!comm)
+    return fail(YAKHIP_EINVAL, "comm_abort: null communicator");
+  if (comm->aborted.exchange(true))
+    return 0;
+  int rc = 0;
+  if (comm->kind == 0 && comm->nccl)
+  {
+    Rccl* lib = nullptr;
+    if ((rc = rccl(&lib)) == 0)
+      rc = check_nccl(lib, lib->CommAbort(comm->nccl), "ncclCommAbort");
+  }
+  if (comm->kind == 1 && comm->group)
+    comm->group->leave();
+  return rc;
+}
+
 int yakhip_comm_destroy(yakhip_comm* comm)
 {
   if (!comm)
@@ -504,18 +546,14 @@ int yakhip_comm_destroy(yakhip_comm* comm)
   int rc = 0;
   if (comm->scratch)
     (void)hipFree(comm->scratch);
-  if (comm->kind == 0 && comm->nccl)
+  if (comm->kind == 0 && comm->nccl && !comm->aborted.load())  // ncclCommAbort has freed an aborted communicator
   {
     Rccl* lib = nullptr;
     if ((rc = rccl(&lib)) == 0)
       rc = check_nccl(lib, lib->CommDestroy(comm->nccl), "ncclCommDestroy");
   }
   if (comm->kind == 1 && comm->group)
-  {
-    std::lock_guard<std::mutex> lock(comm->group->m);
-    comm->group->broken = true;  // ranks still waiting in a barrier give up instead of hanging
-    comm->group->cv.notify_all();
-  }
+    comm->group->leave();
   delete comm;
   return rc;
 }

@@ -151,6 +151,7 @@ void DeviceMemory::swap(DeviceMemory& o)
 }
 bool DeviceMemory::empty() const { return !data_; }
 size_t DeviceMemory::sizeBytes() const { return sizeBytes_; }
+bool DeviceMemory::shared() const { return data_ && owner_.use_count() != 1; }
 
 // ---- DeviceMemory2D ----------------------------------------------------------------------------
 DeviceMemory2D::DeviceMemory2D() : data_(nullptr), step_(0), colsBytes_(0), rows_(0) {}

@@ -4,6 +4,7 @@
 
 #include <yakhip.h>
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <set>
@@ -61,6 +62,10 @@ void ShardedKinFu::worker(Rank* r)
     catch (const std::exception& e)
     {
       err = e.what();
+      // this rank cannot go on: peers that wait for it in an exchange must not wait for ever (local transport: they
+      // wake with YAKHIP_EABORTED; RCCL: this communicator's own collectives end, waitAll() releases the peers')
+      if (r->comm)
+        yakhip_comm_abort(r->comm);
     }
     {
       std::lock_guard<std::mutex> lock(r->m);
@@ -82,16 +87,54 @@ void ShardedKinFu::forEachRank(const std::function<void(int, KinFu&)>& fn)
     r->done = false;
     r->cv.notify_all();
   }
-  std::string first_error;
-  for (Rank* r : ranks_)
-  {
-    std::unique_lock<std::mutex> lock(r->m);
-    r->cv.wait(lock, [&] { return r->done; });
-    if (first_error.empty() && !r->error.empty())
-      first_error = "rank " + std::to_string(r->rank) + ": " + r->error;
-  }
+  const std::string first_error = waitAll(true);
   if (!first_error.empty())
     throw std::runtime_error(first_error);
+}
+
+// Waits for every rank's job.  Once one rank has failed, the ranks still at work may be blocked in a collective that
+// the failed rank will never join: with abort_peers their communicators are aborted from here (ncclCommAbort may be
+// called from another thread; the local transport has been woken by the failed rank's own abort already), so that
+// they come back with an error instead of hanging.  Returns the first error ("" if none).  After a failure the
+// communicators are dead and every later frame fails with YAKHIP_EABORTED: build a new ShardedKinFu.
+std::string ShardedKinFu::waitAll(bool abort_peers)
+{
+  std::string first_error, first_echo;  // (echo: a peer's "the communicator was aborted", the consequence, not the cause)
+  std::vector<bool> finished(ranks_.size(), false), aborted(ranks_.size(), false);
+  size_t left = ranks_.size();
+  bool failed = false;
+  while (left > 0)
+  {
+    for (size_t i = 0; i < ranks_.size(); ++i)
+    {
+      if (finished[i])
+        continue;
+      Rank* r = ranks_[i];
+      std::unique_lock<std::mutex> lock(r->m);
+      // block on the first unfinished rank while all is well, poll once somebody has failed
+      const bool got = r->cv.wait_for(lock, std::chrono::milliseconds(failed ? 1 : 20), [&] { return r->done; });
+      if (got)
+      {
+        finished[i] = true;
+        --left;
+        if (!r->error.empty())
+        {
+          failed = true;
+          const bool echo = r->error.find("left the group") != std::string::npos || r->error.find("was aborted") != std::string::npos;
+          std::string& slot = echo ? first_echo : first_error;
+          if (slot.empty())
+            slot = "rank " + std::to_string(r->rank) + ": " + r->error;
+        }
+      }
+      else if (failed && abort_peers && !aborted[i] && r->comm)
+      {
+        aborted[i] = true;
+        lock.unlock();
+        yakhip_comm_abort(r->comm);
+      }
+    }
+  }
+  return first_error.empty() ? first_echo : first_error;
 }
 
 ShardedKinFu::ShardedKinFu(const KinFuParams& params, const std::vector<int>& devices) : params_(params)
@@ -142,14 +185,9 @@ ShardedKinFu::ShardedKinFu(const KinFuParams& params, const std::vector<int>& de
     r->done = false;
     r->cv.notify_all();
   }
-  std::string first_error;
-  for (Rank* r : ranks_)
-  {
-    std::unique_lock<std::mutex> lock(r->m);
-    r->cv.wait(lock, [&] { return r->done; });
-    if (first_error.empty() && !r->error.empty())
-      first_error = "rank " + std::to_string(r->rank) + ": " + r->error;
-  }
+  // (with RCCL the communicators come into being inside these jobs: a rank that fails before ncclCommInitRank leaves
+  // its peers inside that call, which no abort reaches -- set-up errors there are device errors that hit every rank)
+  const std::string first_error = waitAll(!use_rccl);
   if (!first_error.empty())
   {
     shutdown();

@@ -149,14 +149,24 @@ void TsdfVolume::heldLayers(int& z0, int& z1) const
   z0 = std::max(0, z0 - halo);
   z1 = std::min(dims_[2], z1 + halo);
 }
+// The held range follows the halo, and the halo follows trunc_dist, the voxel size and the two ray-cast factors: the
+// reference's setters never touch the voxels (tsdf_volume.cpp:54-78), so a range that changes under a fused model
+// keeps the model -- the layers old and new range share are carried over, only the layers that are new to the rank
+// start cleared (a halo that grew has not seen the earlier frames: fuse before growing it, or re-fuse), and the
+// surface map is recomputed from the voxels.  Returns true when the layers were allocated fresh (all cleared).
 bool TsdfVolume::ensureSlab()
 {
   int z0, z1;
   heldLayers(z0, z1);
   if (z0 == held_z0_ && z1 == held_z1_ && !data_.empty())
     return false;
+  const bool carry = !data_.empty() && held_z1_ > held_z0_;  // (create() sets the held range empty: fresh)
+  const int old0 = held_z0_, old1 = held_z1_;
+  CudaData old;
+  old.swap(data_);
   held_z0_ = z0, held_z1_ = z1;
-  data_.create((size_t)dims_[0] * (size_t)dims_[1] * (size_t)(z1 - z0) * sizeof(int));
+  const size_t plane = (size_t)dims_[0] * (size_t)dims_[1] * sizeof(int);
+  data_.create(plane * (size_t)(z1 - z0));
   yakhip_volume v = {};
   v.data = data_.ptr<void>();
   const Vec3f vsz = getVoxelSize();
@@ -173,7 +183,13 @@ bool TsdfVolume::ensureSlab()
   v.surface_map = surface_map_.ptr<void>();
   YAK_CHECK(yakhip_clear_volume(context(), &v));
   map_stale_ = false;
-  return true;
+  const int c0 = std::max(z0, old0), c1 = std::min(z1, old1);
+  if (!carry || c1 <= c0)
+    return true;
+  YAK_CHECK(yakhip_copy(context(), data_.ptr<char>() + plane * (size_t)(c0 - z0), old.ptr<char>() + plane * (size_t)(c0 - old0),
+                        plane * (size_t)(c1 - c0)));
+  YAK_CHECK(yakhip_surface_map_rebuild(context(), &v));
+  return false;
 }
 yakhip_volume TsdfVolume::view() const
 {
@@ -191,13 +207,17 @@ yakhip_volume TsdfVolume::view() const
 }
 // Someone may have written voxels behind the class's back (the non-const data() handle, swap): the map is
 // recomputed from the voxels before the next ray cast consults it.
+// Staleness is sticky for as long as somebody outside still holds the storage (CudaData copies alias, and wrapped
+// user memory is the user's): such a handle can be written through at any time, also after a ray cast has rebuilt
+// the map, so every consult rebuilds until the last outside handle is gone (the reference puts no constraint on
+// what a caller does with data(), tsdf_volume.cpp:50-51).
 void TsdfVolume::freshSurfaceMap()
 {
   if (!map_stale_)
     return;
   const yakhip_volume v = view();
   YAK_CHECK(yakhip_surface_map_rebuild(context(), &v));
-  map_stale_ = false;
+  map_stale_ = data_.shared();
 }
 const void* TsdfVolume::ownedData(size_t& voxels) const
 {
@@ -266,7 +286,7 @@ void TsdfVolume::clear()  // :80-87
     return;  // freshly allocated layers are cleared
   const yakhip_volume v = view();
   YAK_CHECK(yakhip_clear_volume(context(), &v));
-  map_stale_ = false;
+  map_stale_ = map_stale_ && data_.shared();  // a writable handle that is still out there can be written through again
 }
 
 // :89-108.  vol2cam = camera_pose^-1 * pose_; the device layer takes it as row-major R and t
