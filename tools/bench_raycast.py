@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--no-bands", action="store_true")
     ap.add_argument("--bands", type=int, default=None)
     ap.add_argument("--empty", action="store_true", help="ray cast the cleared volume")
+    ap.add_argument("--segments", type=int, default=None, help="waves per ray with the surface map (1, 2, 4)")
     args = ap.parse_args()
     import torch
 
@@ -51,6 +52,8 @@ def main():
         ctx.set_option("raycast_bands", 0)
     if args.bands is not None:
         ctx.set_option("raycast_bands", args.bands)
+    if args.segments is not None:
+        ctx.set_option("raycast_segments", args.segments)
     n = args.n
     dims, vs, tr = synth.volume_geometry(n)
     vol = torch.zeros(n ** 3, dtype=torch.int32, device="cuda")

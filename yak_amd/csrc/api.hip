@@ -138,6 +138,10 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->chunk_order = -1;
   ctx->surface_skip = 1;
   ctx->raycast_bands = -1;
+  ctx->raycast_segments = 0;
+  if (const char* e = getenv("YAK_HIP_RAYCAST_SEGMENTS"))  // (tuning / tests: 1, 2 or 4 waves per ray)
+    if ((e[0] == '1' || e[0] == '2' || e[0] == '4') && e[1] == 0)
+      ctx->raycast_segments = e[0] - '0';
   ctx->chunk_min = 0;
   ctx->chunk_ramp = 0;
   ctx->checkpoint = 1;
@@ -403,6 +407,13 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
   if (strcmp(key, "raycast_bands") == 0)
   {
     ctx->raycast_bands = (int)value;  // -1 automatic, 0 image order, 1 XCD bands, >= 2 scattered with about this stride
+    return 0;
+  }
+  if (strcmp(key, "raycast_segments") == 0)
+  {
+    if (value != 0 && value != 1 && value != 2 && value != 4)
+      return fail(YAKHIP_EINVAL, "set_option(raycast_segments): 0 (default), 1, 2 or 4");
+    ctx->raycast_segments = (int)value;
     return 0;
   }
   if (strcmp(key, "surface_skip") == 0)

@@ -34,6 +34,7 @@ constexpr int kUnrollPlain = 4;
 #ifndef YAK_RAYCAST_UNROLL_SKIP
 #define YAK_RAYCAST_UNROLL_SKIP 8
 #endif
+constexpr int kDefaultSegments = 1;  // waves per ray when the surface map is consulted (raycast_kernel, SEG)
 constexpr int kMaxSkipWords = 8192;  // 32 KiB of LDS: 2^18 bricks, e.g. 1024^3 voxels or a 2048 x 2048 x 256 slab
 
 template <bool IDX32>
@@ -130,6 +131,17 @@ __device__ __forceinline__ float fetch_tsdf_skip(const RaycastParams& p, rsrc_t 
   return half_bits_to_float(word & 0xffffu);
 }
 
+// The brick bit alone, whole volume: is the sample's brick marked?  (fetch_tsdf_skip's own index arithmetic.)
+__device__ __forceinline__ bool sample_brick_marked(const RaycastParams& p, const uint32_t* map_lds, float px, float py, float pz)
+{
+  const int x = clamp_index((int)__builtin_rintf(px * p.ivx), p.X - 1);
+  const int y = clamp_index((int)__builtin_rintf(py * p.ivy), p.Y - 1);
+  const int z = clamp_index((int)__builtin_rintf(pz * p.ivz), p.Z - 1);
+  const uint32_t b = (uint32_t)(x >> kSkipShift) +
+                     __umul24((uint32_t)p.skip_x, (uint32_t)(y >> kSkipShift) + __umul24((uint32_t)p.skip_y, (uint32_t)(z >> kSkipShift)));
+  return (map_lds[b >> 5] >> (b & 31u)) & 1u;
+}
+
 // tsdf_volume.cu:167-192: trilinear tap, argument in voxel units
 template <bool IDX32, bool SLAB>
 __device__ float interpolate(const RaycastParams& p, float cfx, float cfy, float cfz, bool& held)
@@ -219,9 +231,19 @@ __device__ __forceinline__ void average_block(int lane, int right, int down, flo
   }
 }
 
-template <bool IDX32, bool SLAB, bool SKIP>
+// SEG > 1 (whole volume with the surface map only): the march of every ray is cut into SEG segments of its pair
+// sequence and SEG waves of the workgroup march one each -- the rule of the slab composite inside one GPU.  A wave
+// replays the march's arithmetic up to its first pair without fetching anything, examines its own pairs as the
+// whole march would have, and the smallest pair index that ends the march wins (tsdf_volume.cu:320-351 stops at the
+// first such pair): same image, the longest ray costs a SEG-th.  The workgroup then covers 4 / SEG tiles of 8 x 8.
+template <bool IDX32, bool SLAB, bool SKIP, int SEG>
 __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, int tiles_x, int n_tiles, int per_xcd)
 {
+  static_assert(SEG == 1 || (SKIP && !SLAB && (SEG == 2 || SEG == 4)), "segments: whole volume with the surface map");
+  constexpr int kNone = 0x7fffffff;
+  constexpr int kSub = SEG > 1 ? 4 / SEG : 1;             // tiles of 8 x 8 pixels per workgroup
+  __shared__ int seg_key[SEG > 1 ? kSub * 64 : 1];        // per pixel: the smallest pair index that ended a march so far (x 2)
+  __shared__ float seg_out[SEG > 1 ? kSub * 7 * 64 : 1];  // the winner's vertex, normal and hit flag
   // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs; give each XCD a
   // contiguous run of tiles (a band of the image) so that its L2 sees one part of the volume.
   const int bid = (int)blockIdx.x;
@@ -235,18 +257,25 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
   RC_CLOCK(rc_t0);
 #endif
   extern __shared__ uint32_t map_lds[];
+  // The surface map's words go to LDS; their loads are sent off here and waited for after the ray has been set up
+  // (a sqrt and five correctly rounded divisions: the longest stretch of the kernel without a memory access).
+  constexpr int kMapRegs = 8;  // words per thread in flight (a 512^3 volume's map: 1040 words, five a thread)
+  uint32_t map_regs[kMapRegs];
   if constexpr (SKIP)
   {
-    for (int i = (int)threadIdx.x; i < p.skip_words + p.cell_words; i += 256)
-      map_lds[i] = p.skip[i];
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kMapRegs; ++j)
+    {
+      const int i = (int)threadIdx.x + j * 256;
+      map_regs[j] = i < p.skip_words + p.cell_words ? p.skip[i] : 0u;
+    }
   }
   const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
   const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-  const int x = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-  const int y = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
-  if (x >= p.cols || y >= p.rows)
-    return;
+  const int sub = SEG > 1 ? wave / SEG : 0, seg = SEG > 1 ? wave % SEG : 0;
+  const int x = SEG > 1 ? tile_x * (8 * kSub) + sub * 8 + (lane & 7) : tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+  const int y = SEG > 1 ? tile_y * 8 + (lane >> 3) : tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  const bool valid = x < p.cols && y < p.rows;  // (a lane outside the image stays until the barrier below)
 
   RC_CLOCK(rc_t1);
   RC_CLOCK(rc_t2);
@@ -270,7 +299,7 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
   tmin = fmaxf(0.f, tmin);
 
   // 0 = marching, 1 = zero crossing found, 2 = finished without one
-  int state = tmin < tmax ? 0 : 2;
+  int state = tmin < tmax && valid ? 0 : 2;
 
   // tsdf_volume.cu:316-318
   const float ts = p.time_step;
@@ -283,6 +312,51 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
   // tsdf_volume.cu:320-351, kUnroll samples in flight per trip.  Slab mode: a pair is examined only if
   // its first sample lies in an owned layer; `pair` counts the pairs of the global march.
   int pair = 0;
+  // this wave's pairs [k_lo, k_hi) of the march: the same split in every wave of a pixel (same arithmetic, same lane)
+  int k_hi = kNone;
+  if constexpr (SEG > 1)
+  {
+    const float span = (tmax - tmin) * __builtin_amdgcn_rcpf(ts);  // about the number of pairs inside the volume
+    const int n_tot = state == 0 ? (int)fminf(fmaxf(span, 0.f), 1.0e6f) + 1 : 0;
+    const int k_lo = n_tot * seg / SEG;
+    k_hi = seg == SEG - 1 ? kNone : n_tot * (seg + 1) / SEG;
+    // up to its first pair a wave replays what the march does between events: the time test, the rounded additions
+    f32x2 pxy = { nx, ny }, pzt = { nz, tcurr };
+    const f32x2 sxy = { sx, sy }, szt = { sz, ts };
+    int done = 0;
+    if (state == 0)
+      for (; done < k_lo; ++done)
+      {
+        if (!(pzt.y < tmax))
+        {
+          state = 2;
+          break;
+        }
+        pxy += sxy;
+        pzt += szt;
+      }
+    nx = pxy.x, ny = pxy.y, nz = pzt.x, tcurr = pzt.y;
+    pair = done;
+  }
+  if constexpr (SKIP)
+  {
+#pragma unroll
+    for (int j = 0; j < kMapRegs; ++j)
+    {
+      const int i = (int)threadIdx.x + j * 256;
+      if (i < p.skip_words + p.cell_words)
+        map_lds[i] = map_regs[j];
+    }
+    for (int i = (int)threadIdx.x + kMapRegs * 256; i < p.skip_words + p.cell_words; i += 256)
+      map_lds[i] = p.skip[i];
+    if constexpr (SEG > 1)
+      if ((int)threadIdx.x < kSub * 64)
+        seg_key[threadIdx.x] = kNone;
+    __syncthreads();
+  }
+  if constexpr (SEG == 1)
+    if (!valid)
+      return;  // (SEG > 1: the lane stays for the workgroup's later barriers, marches nothing and writes nothing)
   if (state == 0)
   {
     bool own_next = true, scratch = true, skip_next = false;
@@ -317,12 +391,14 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
         const float igx = __builtin_amdgcn_rcpf(gx), igy = __builtin_amdgcn_rcpf(gy), igz = __builtin_amdgcn_rcpf(gz);
         const float big = 3.0e38f;
         // time at which the ray crosses into the next cell along each axis, and the time between crossings
-        float tx = gx > 0.f ? tmin + ((float)((cxi + 1) << 6) - ux) * igx : (gx < 0.f ? tmin + ((float)(cxi << 6) - ux) * igx : big);
-        float ty = gy > 0.f ? tmin + ((float)((cyi + 1) << 6) - uy) * igy : (gy < 0.f ? tmin + ((float)(cyi << 6) - uy) * igy : big);
-        float tz = gz > 0.f ? tmin + ((float)((czi + 1) * 64) - uz) * igz : (gz < 0.f ? tmin + ((float)(czi * 64) - uz) * igz : big);
+        // (t0: the march time of the sample the walk starts from -- tmin, or a later segment's first sample)
+        const float t0 = tcurr;
+        float tx = gx > 0.f ? t0 + ((float)((cxi + 1) << 6) - ux) * igx : (gx < 0.f ? t0 + ((float)(cxi << 6) - ux) * igx : big);
+        float ty = gy > 0.f ? t0 + ((float)((cyi + 1) << 6) - uy) * igy : (gy < 0.f ? t0 + ((float)(cyi << 6) - uy) * igy : big);
+        float tz = gz > 0.f ? t0 + ((float)((czi + 1) * 64) - uz) * igz : (gz < 0.f ? t0 + ((float)(czi * 64) - uz) * igz : big);
         const float ex = 64.f * __builtin_fabsf(igx), ey = 64.f * __builtin_fabsf(igy), ez = 64.f * __builtin_fabsf(igz);
         const int stx = gx > 0.f ? 1 : -1, sty = gy > 0.f ? 1 : -1, stz = gz > 0.f ? 1 : -1;
-        float t_free = tmin;
+        float t_free = t0;
         for (int guard = 0; guard < 4096; ++guard)
         {
           if ((unsigned)cxi >= (unsigned)p.cell_x || (unsigned)cyi >= (unsigned)p.cell_y)
@@ -349,11 +425,25 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
           if (!(t_free < tmax))
             break;
         }
-        const float room = (fminf(t_free, tmax) - tmin) / ts - 2.f;
-        const int steps = room > 0.f ? (int)fminf(room, 1.0e6f) : 0;
+        const float room = (fminf(t_free, tmax) - t0) / ts - 2.f;
+        int steps = room > 0.f ? (int)fminf(room, 1.0e6f) : 0;
+        if constexpr (SEG > 1)
+          steps = min(steps, max(k_hi - pair, 0));  // (not beyond the segment: its end is examined in the march)
         f32x2 pxy = { nx, ny }, pzt = { nz, tcurr };
         const f32x2 sxy = { sx, sy }, szt = { sz, ts };
         int done = 0;
+        // four steps at a time while all four pass the time test (the times rise: the fourth step's test decides),
+        // then step by step -- the same additions in the same order either way
+        while (done + 4 <= steps)
+        {
+          const f32x2 a1 = pxy + sxy, b1 = pzt + szt;
+          const f32x2 a2 = a1 + sxy, b2 = b1 + szt;
+          const f32x2 a3 = a2 + sxy, b3 = b2 + szt;
+          if (!(b3.y < tmax))
+            break;
+          pxy = a3 + sxy, pzt = b3 + szt;
+          done += 4;
+        }
         for (; done < steps; ++done)
         {
           if (!(pzt.y < tmax))
@@ -380,7 +470,60 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
     {
       RC_COUNT(rc_trips);
       RC_CLOCK(rc_trip0);
+      if constexpr (SEG > 1)
+      {
+        // an earlier segment's march has ended at a pair before this one: nothing here can win any more
+        if (__hip_atomic_load(&seg_key[sub * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2 * pair)
+        {
+          state = 2;
+          break;
+        }
+      }
       constexpr int kUnroll = SKIP ? YAK_RAYCAST_UNROLL_SKIP : kUnrollPlain;
+      if constexpr (SKIP && !SLAB)
+      {
+        // A look at the bricks before anything else.  Inside a marked cell most samples still lie in unmarked bricks
+        // (six trips in seven fetch nothing): if none of this trip's samples, in any lane still marching, lies in a
+        // marked brick and the sample stood on is not negative, every value of the trip reads as +0 and no pair can end
+        // the march (tsdf_volume.cu:326-331 needs a negative sample) -- only the march's own arithmetic is left, the
+        // time test and the rounded additions.  (Measured: working out the voxel offsets here as well, for the full
+        // trip to reuse, costs the quiet trips more than it saves the others.)
+        float bx = nx, by = ny, bz = nz;
+        bool marked = tsdf_next < 0.f;
+#pragma unroll
+        for (int k = 0; k < kUnroll; ++k)
+        {
+          bx += sx;
+          by += sy;
+          bz += sz;
+          marked = marked | sample_brick_marked(p, map_lds, bx, by, bz);
+        }
+        if (__ballot(marked) == 0ull)
+        {
+          // the times of the trip's steps: rising, so the last test decides them all
+          float tl = tcurr;
+#pragma unroll
+          for (int k = 0; k < kUnroll - 1; ++k)
+            tl += ts;
+          if (tl < tmax && (SEG == 1 || pair + kUnroll <= k_hi))
+            tcurr = tl + ts, pair += kUnroll;
+          else
+          {
+#pragma unroll
+            for (int k = 0; k < kUnroll; ++k)
+            {
+              const bool late = !(tcurr < tmax) | (SEG > 1 && pair >= k_hi);
+              const bool on = (state == 0) & !late;
+              tcurr = on ? tcurr + ts : tcurr;
+              pair += on ? 1 : 0;
+              state = (state == 0 && late) ? 2 : state;
+            }
+          }
+          nx = bx, ny = by, nz = bz;
+          tsdf_next = 0.f, skip_next = true;  // an unmarked brick's sample: +0, not fetched
+          continue;
+        }
+      }
       float qx[kUnroll], qy[kUnroll], qz[kUnroll], f[kUnroll];
       bool own[kUnroll], held[kUnroll], skip[kUnroll];
       float ax = nx, ay = ny, az = nz;
@@ -428,7 +571,7 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
         {
           // (& and |, not && and ||: masks, no short cuts)
           const bool marching = state == 0;
-          const bool late = !(tcurr < tmax);
+          const bool late = !(tcurr < tmax) | (SEG > 1 && pair >= k_hi);  // (a segment's end: "no event", like the ray's)
           const bool abort = own_c & (fc < 0.f) & (f[k] > 0.f), crossing = own_c & (fc > 0.f) & (f[k] < 0.f);
           const int verdict = late ? 2 : (abort ? 3 : (crossing ? 1 : 0));
           const bool on = marching & !(late | abort | crossing);
@@ -500,7 +643,17 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
   const float qnan = __builtin_nanf("");
   float vx = qnan, vy = qnan, vz = qnan, vw = qnan, n0 = qnan, n1 = qnan, n2 = qnan, n3 = qnan;
   bool hit = false, deferred = false;
-  if (state == 1)
+  bool winner = true;
+  if constexpr (SEG > 1)
+  {
+    // the pair that ended this wave's march against the other segments' of the same pixel: the smallest ends the ray
+    const int key = (state == 1 || state == 3) ? 2 * pair : kNone;
+    if (key != kNone)
+      atomicMin(&seg_key[sub * 64 + lane], key);
+    __syncthreads();
+    winner = valid && seg_key[sub * 64 + lane] == key && (key != kNone || seg == 0);  // (no event anywhere: segment 0 reports that)
+  }
+  if (state == 1 && winner)
   {
     // tsdf_volume.cu:333-348
     bool held_bracket = true, held_normal = true;
@@ -532,6 +685,22 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
     }
   }
 
+  if constexpr (SEG > 1)
+  {
+    // the winner's pixel goes to the tile's first wave, which writes the tile (and averages it for the pyramid)
+    float* out = &seg_out[sub * 7 * 64 + lane];
+    if (winner)
+    {
+      out[0 * 64] = vx, out[1 * 64] = vy, out[2 * 64] = vz, out[3 * 64] = n0, out[4 * 64] = n1, out[5 * 64] = n2;
+      out[6 * 64] = hit ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (seg != 0 || !valid)
+      return;
+    vx = out[0 * 64], vy = out[1 * 64], vz = out[2 * 64], n0 = out[3 * 64], n1 = out[4 * 64], n2 = out[5 * 64];
+    hit = out[6 * 64] != 0.f;
+    vw = hit ? 0.f : qnan, n3 = hit ? 0.f : qnan;
+  }
   // tsdf_volume.cu:298 (defaults) and :346-347 / :279-280 (hit)
   float4* nrow = (float4*)(p.normals + (size_t)y * p.normals_pitch);
   nrow[x] = make_float4(n0, n1, n2, n3);
@@ -794,14 +963,21 @@ int launch_raycast_resolve(yakhip_ctx* ctx, const RaycastParams& p)
 
 int launch_raycast(yakhip_ctx* ctx, const RaycastParams& p)
 {
-  const int tiles_x = (p.cols + 15) / 16, tiles_y = (p.rows + 15) / 16;
+  const bool slab = p.keys != nullptr;
+  // the surface map travels in LDS: volumes whose map is too large for that are marched without it
+  // (and it does its index arithmetic in 24 bits: fetch_tsdf_skip)
+  const bool skip = p.skip != nullptr && p.skip_words + p.cell_words <= kMaxSkipWords && p.vol_bytes < 0x80000000ull &&
+                    p.X < (1 << 24) && p.Y < (1 << 24) && (long long)p.Y * p.z_held <= (1ll << 24) && ctx->surface_skip;
+  // segments per ray (raycast_kernel, SEG): whole volume with the surface map only
+  const int seg = skip && !slab ? (ctx->raycast_segments > 0 ? ctx->raycast_segments : kDefaultSegments) : 1;
+  const int tile_w = seg == 1 ? 16 : 32 / seg, tile_h = seg == 1 ? 16 : 8;  // pixels per workgroup
+  const int tiles_x = (p.cols + tile_w - 1) / tile_w, tiles_y = (p.rows + tile_h - 1) / tile_h;
   const long long n_tiles_ll = (long long)tiles_x * tiles_y;
   if (n_tiles_ll > 0x7ffffff0ll / 8)
     return fail(YAKHIP_ERANGE, "raycast: image too large");
   const int n_tiles = (int)n_tiles_ll;
   const int per_xcd = (n_tiles + 7) / 8;
   const dim3 grid((unsigned)(per_xcd * 8));
-  const bool slab = p.keys != nullptr;
   const bool idx32 =
       (unsigned long long)p.X * (unsigned long long)p.Y * (unsigned long long)(slab ? p.z_held : p.Z) <= (1ull << 30);
 
@@ -809,18 +985,18 @@ int launch_raycast(yakhip_ctx* ctx, const RaycastParams& p)
   int rc = timing_begin(ctx, &ev);
   if (rc != 0)
     return rc;
-  // the surface map travels in LDS: volumes whose map is too large for that are marched without it
-  // (and it does its index arithmetic in 24 bits: fetch_tsdf_skip)
-  const bool skip = p.skip != nullptr && p.skip_words + p.cell_words <= kMaxSkipWords && p.vol_bytes < 0x80000000ull &&
-                    p.X < (1 << 24) && p.Y < (1 << 24) && (long long)p.Y * p.z_held <= (1ll << 24) && ctx->surface_skip;
   const size_t lds = skip ? (size_t)(p.skip_words + p.cell_words) * 4u : 0;
-#define YAK_RAYCAST_LAUNCH(I, S)                                                                                    \
-  do                                                                                                               \
-  {                                                                                                                \
-    if (skip)                                                                                                      \
-      hipLaunchKernelGGL((raycast_kernel<I, S, true>), grid, dim3(256), lds, ctx->stream, p, tiles_x, n_tiles, per_xcd_arg);  \
-    else                                                                                                           \
-      hipLaunchKernelGGL((raycast_kernel<I, S, false>), grid, dim3(256), lds, ctx->stream, p, tiles_x, n_tiles, per_xcd_arg); \
+#define YAK_RAYCAST_LAUNCH(I, S)                                                                                              \
+  do                                                                                                                         \
+  {                                                                                                                          \
+    if (skip && !S && seg == 4)                                                                                              \
+      hipLaunchKernelGGL((raycast_kernel<I, false, true, 4>), grid, dim3(256), lds, ctx->stream, p, tiles_x, n_tiles, per_xcd_arg); \
+    else if (skip && !S && seg == 2)                                                                                         \
+      hipLaunchKernelGGL((raycast_kernel<I, false, true, 2>), grid, dim3(256), lds, ctx->stream, p, tiles_x, n_tiles, per_xcd_arg); \
+    else if (skip)                                                                                                           \
+      hipLaunchKernelGGL((raycast_kernel<I, S, true, 1>), grid, dim3(256), lds, ctx->stream, p, tiles_x, n_tiles, per_xcd_arg);    \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((raycast_kernel<I, S, false, 1>), grid, dim3(256), lds, ctx->stream, p, tiles_x, n_tiles, per_xcd_arg);   \
   } while (0)
   // XCD bands pay while the march fetches (each L2 sees one part of the volume: 0.057 against 0.070 ms along z);
   // with the surface map a tile costs its hits, which come in patches of the image, and plain image order spreads
