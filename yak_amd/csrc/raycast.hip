@@ -466,6 +466,7 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
       }
     }
     RC_CLOCK(rc_t2);
+    bool look_first = true;  // (wave-uniform)
     while (state == 0)
     {
       RC_COUNT(rc_trips);
@@ -490,15 +491,20 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
         // trip to reuse, costs the quiet trips more than it saves the others.)
         float bx = nx, by = ny, bz = nz;
         bool marked = tsdf_next < 0.f;
-#pragma unroll
-        for (int k = 0; k < kUnroll; ++k)
+        if (look_first)
         {
-          bx += sx;
-          by += sy;
-          bz += sz;
-          marked = marked | sample_brick_marked(p, map_lds, bx, by, bz);
+#pragma unroll
+          for (int k = 0; k < kUnroll; ++k)
+          {
+            bx += sx;
+            by += sy;
+            bz += sz;
+            marked = marked | sample_brick_marked(p, map_lds, bx, by, bz);
+          }
         }
-        if (__ballot(marked) == 0ull)
+        // (a wave that has just fetched does not look first: beside a surface one trip after the other fetches; it
+        // looks again after a full trip that found every sample of every lane in an unmarked brick)
+        if (look_first && __ballot(marked) == 0ull)
         {
           // the times of the trip's steps: rising, so the last test decides them all
           float tl = tcurr;
@@ -523,6 +529,7 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
           tsdf_next = 0.f, skip_next = true;  // an unmarked brick's sample: +0, not fetched
           continue;
         }
+        look_first = false;
       }
       float qx[kUnroll], qy[kUnroll], qz[kUnroll], f[kUnroll];
       bool own[kUnroll], held[kUnroll], skip[kUnroll];
@@ -539,6 +546,14 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
           f[k] = fetch_tsdf_skip<SLAB>(p, rs, map_lds, ax, ay, az, own[k], held[k], skip[k]);
         else
           f[k] = fetch_tsdf<IDX32, SLAB>(p, ax, ay, az, own[k], held[k]);
+      }
+      if constexpr (SKIP && !SLAB)
+      {
+        bool all_skipped = true;
+#pragma unroll
+        for (int k = 0; k < kUnroll; ++k)
+          all_skipped = all_skipped & skip[k];
+        look_first = __ballot(!all_skipped) == 0ull;
       }
       if constexpr (SKIP)
       {
