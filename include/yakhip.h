@@ -127,6 +127,9 @@ const char* yakhip_last_error(void);
  * layer 0: a chunk that starts at layer zs is about zs / ramp layers long, at least chunk_min; 0 = auto, ramp -1 = all alike),
  * "icp_poll" (0/1: yakhip_icp_estimate polls pinned memory for its result / copies and
  * synchronises), "surface_skip" (0/1: the ray cast consults / ignores yakhip_volume.surface_map),
+ * "raycast_segments" (waves per ray where the surface map is consulted: 1 (= 0, the default) one wave marches the whole ray, 2 or 4 cut
+ * its sample pairs into segments marched side by side, the first pair that ends a march wins -- same images, measured slower: DESIGN 3.6;
+ * also YAK_HIP_RAYCAST_SEGMENTS in the environment),
  * "brick_stats" (0/1, see yakhip_ctx_brick_stats), "composite_capacity" (list slots of yakhip_raycast_sharded's second step, 0 = auto),
  * "defer_mixed" (how yakhip_integrate launches: 0 one kernel, every workgroup walking its own bricks; 2 two kernels wherever the
  * 16-byte layout allows -- the brick test for the whole grid first, then the live bricks' parts dealt out evenly to a fixed number

@@ -126,3 +126,45 @@ def test_pyramid_rejects_bad_arguments(gpu_ctx):
     with pytest.raises(capi.YakHipError):
         call(slab, 16, 16, half, None)                                        # whole volume only
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("segments", [2, 4])
+@pytest.mark.parametrize("rows,cols,pad", [(synth.ROWS, synth.COLS, 0), (50, 70, 26), (37, 53, 3), (9, 14, 2)])
+def test_rays_marched_in_segments_give_the_same_maps(segments, rows, cols, pad):
+    """Option raycast_segments (include/yakhip.h): every ray's pair sequence cut over 2 or 4 waves, the smallest pair
+    index that ends a march wins -- tsdf_volume.cu:320-351 stops at the first such pair.  Full-size maps, both pyramid
+    levels and the depth overload must carry the bits of the one-wave march (which the oracle pins elsewhere), image
+    sizes that fill no tile included."""
+    vol_h, dims, vs, tr = fused_volume(128, [0, 10, 20, 30, 40, 50, 120, 250], scene="s2")
+    vol = torch.from_numpy(vol_h.view(np.int32)).cuda()
+    plain = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT)
+    smap = torch.zeros(capi.surface_map_bytes(plain) // 4, dtype=torch.int32, device="cuda")
+    desc = capi.volume_desc(vol.data_ptr(), dims, vs, tr, synth.MAX_WEIGHT, surface_map=smap.data_ptr())
+    s = cols / synth.COLS
+    intr = tuple(v * s for v in synth.INTR[:3]) + (synth.INTR[3] * rows / synth.ROWS,)
+    ctx = capi.Context(0)
+    try:
+        ctx.surface_map_rebuild(desc)
+        for view in (5, 133, 222):
+            _, R_v2c, t_v2c = synth.scene_s2(view)
+            R, t = cam2vol(R_v2c, t_v2c)
+            pose = (np.asarray(R).reshape(-1), t, np.asarray(R_v2c).reshape(-1), intr)
+            ctx.set_option("raycast_segments", 1)
+            want, _ = _run(ctx, desc, R, t, R_v2c, intr, rows, cols, pad, 3)
+            dn = _maps(rows, cols, pad)[0]
+            dd = torch.full((rows, cols + pad), 7, dtype=torch.int16, device="cuda")
+            ctx.raycast_depth(desc, *pose, dd.data_ptr(), (cols + pad) * 2, dn.data_ptr(), (cols + pad) * 16, rows, cols)
+            ctx.set_option("raycast_segments", segments)
+            got, _ = _run(ctx, desc, R, t, R_v2c, intr, rows, cols, pad, 3)
+            dn2 = _maps(rows, cols, pad)[0]
+            dd2 = torch.full((rows, cols + pad), 7, dtype=torch.int16, device="cuda")
+            ctx.raycast_depth(desc, *pose, dd2.data_ptr(), (cols + pad) * 2, dn2.data_ptr(), (cols + pad) * 16, rows, cols)
+            torch.cuda.synchronize()
+            _check(got, want)
+            assert torch.equal(dd, dd2) and torch.equal(dn.view(torch.int32), dn2.view(torch.int32))
+            if rows == synth.ROWS:
+                assert (~np.isnan(want[0][0].view(np.float32)[..., 0])).sum() > 10000
+        with pytest.raises(capi.YakHipError):
+            ctx.set_option("raycast_segments", 3)
+    finally:
+        ctx.close()
