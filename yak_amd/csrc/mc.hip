@@ -70,9 +70,11 @@ __device__ __forceinline__ unsigned cube_index(unsigned a_lo, unsigned b_lo, uns
          (((b_hi >> 2) & 1u) << 4) | (((a_hi >> 2) & 1u) << 5) | ((a_hi & 1u) << 6) | ((b_hi & 1u) << 7);
 }
 
+// EMIT: launched over the tiles that hold triangles only -- wave k takes list entry k = {tile, first slot}
+// (mc_compact_kernel), n_live of them; the count pass over every tile of the slab.
 template <bool EMIT>
-__global__ __launch_bounds__(256) void mc_kernel(const McParams p, uint32_t* counts, const uint32_t* local_offsets,
-                                                 const unsigned long long* block_bases, float* triangles)
+__global__ __launch_bounds__(256) void mc_kernel(const McParams p, uint32_t* counts, const unsigned long long* list,
+                                                 unsigned long long n_live, float* triangles)
 {
   // The case table in LDS.  The emit pass keeps a copy per wave and fills it only after the wave knows that
   // its tile holds triangles: nearly all of its waves leave at once, and a workgroup barrier behind a
@@ -102,13 +104,27 @@ __global__ __launch_bounds__(256) void mc_kernel(const McParams p, uint32_t* cou
   const unsigned wg =
       !EMIT && blockIdx.x < per_xcd * 8u ? (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u : blockIdx.x;
   const unsigned gy = (unsigned)(p.ny + 3) / 4u;
-  const int xt = (int)(wg % (unsigned)p.nx), yt = (int)((wg / (unsigned)p.nx) % gy) * 4 + wave,
-            zc = (int)(wg / ((unsigned)p.nx * gy));
-  if (yt >= p.ny)
-    return;
   const int walk = EMIT ? p.z_sub : p.z_chunk;
   const size_t tile_stride = (size_t)p.ny * p.nx;
-  size_t tile = ((size_t)zc * (size_t)(walk / p.z_sub) * p.ny + yt) * p.nx + xt;  // first tile of this wave
+  int xt, yt, zc;
+  size_t tile;  // first tile of this wave
+  unsigned long long out = 0;
+  if (EMIT)
+  {
+    const unsigned long long k = (unsigned long long)blockIdx.x * 4ull + (unsigned long long)wave;
+    if (k >= n_live)
+      return;
+    tile = (size_t)list[2 * k];
+    out = list[2 * k + 1];
+    xt = (int)(tile % (size_t)p.nx), yt = (int)((tile / (size_t)p.nx) % (size_t)p.ny), zc = (int)(tile / tile_stride);
+  }
+  else
+  {
+    xt = (int)(wg % (unsigned)p.nx), yt = (int)((wg / (unsigned)p.nx) % gy) * 4 + wave, zc = (int)(wg / ((unsigned)p.nx * gy));
+    if (yt >= p.ny)
+      return;
+    tile = ((size_t)zc * (size_t)(walk / p.z_sub) * p.ny + yt) * p.nx + xt;
+  }
   if (!EMIT && p.map)
   {
     // A cube has triangles only if one of its corners is negative (cases 0 and 255 have none), and a brick whose
@@ -133,12 +149,8 @@ __global__ __launch_bounds__(256) void mc_kernel(const McParams p, uint32_t* cou
       return;
     }
   }
-  unsigned long long out = 0;
   if (EMIT)
   {
-    if (counts[tile] == 0)
-      return;
-    out = block_bases[tile / kScanBlock] + local_offsets[tile];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       table_lds[wave][lane + 64 * i] = yak_mc_case_table[lane + 64 * i];
@@ -369,45 +381,77 @@ __global__ __launch_bounds__(256) void mc_kernel(const McParams p, uint32_t* cou
 // Exclusive scan of the tile counts in two small launches: every workgroup scans kScanBlock counts
 // (4 per thread, one 16-byte load) into offsets local to the block and publishes the block's sum; one
 // workgroup then scans the block sums.  The emit pass adds the two.
+// With live_local / block_live (marching cubes): the same scan over "this tile holds triangles", packed into the upper
+// half of the scanned word (a block holds 1024 tiles, its triangles stay far below 2^32) -- the emit pass is launched
+// over the live tiles only (mc_compact_kernel).
 __global__ __launch_bounds__(256) void mc_scan_local_kernel(const uint32_t* counts, uint32_t* local_offsets, size_t n,
-                                                            unsigned long long* block_sums)
+                                                            unsigned long long* block_sums, uint32_t* live_local,
+                                                            unsigned long long* block_live)
 {
-  __shared__ uint32_t wave_sum[4];
+  __shared__ unsigned long long wave_sum[4];
   const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
   const size_t base = (size_t)blockIdx.x * kScanBlock + (size_t)threadIdx.x * 4;
   uint32_t c[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     c[i] = base + i < n ? counts[base + i] : 0u;
-  const uint32_t mine = c[0] + c[1] + c[2] + c[3];
-  uint32_t incl = mine;
+  auto packed = [](uint32_t v) { return (unsigned long long)v | ((unsigned long long)(v != 0u) << 32); };
+  const unsigned long long mine = packed(c[0]) + packed(c[1]) + packed(c[2]) + packed(c[3]);
+  unsigned long long incl = mine;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1)
   {
-    const uint32_t up = __shfl_up(incl, off, 64);
+    const unsigned long long up = __shfl_up(incl, off, 64);
     if (lane >= off)
       incl += up;
   }
   if (lane == 63)
     wave_sum[wave] = incl;
   __syncthreads();
-  uint32_t before = incl - mine;
+  unsigned long long before = incl - mine;
   for (int w = 0; w < wave; ++w)
     before += wave_sum[w];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
   {
     if (base + i < n)
-      local_offsets[base + i] = before;
-    before += c[i];
+    {
+      local_offsets[base + i] = (uint32_t)before;
+      if (live_local)
+        live_local[base + i] = (uint32_t)(before >> 32);
+    }
+    before += packed(c[i]);
   }
   if (threadIdx.x == 255)
-    block_sums[blockIdx.x] = before;
+  {
+    block_sums[blockIdx.x] = before & 0xffffffffull;
+    if (block_live)
+      block_live[blockIdx.x] = before >> 32;
+  }
+}
+
+// The live tiles in tile order, each with the slot of its first triangle: entry k = {tile, slot} of the k-th tile that
+// holds triangles.  One thread per tile, after both scans.
+__global__ __launch_bounds__(256) void mc_compact_kernel(const uint32_t* counts, const uint32_t* local_offsets,
+                                                         const unsigned long long* block_bases, const uint32_t* live_local,
+                                                         const unsigned long long* block_live, size_t n,
+                                                         unsigned long long* list)
+{
+  const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= n || counts[i] == 0u)
+    return;
+  const size_t b = i / kScanBlock;
+  const unsigned long long k = block_live[b] + live_local[i];
+  list[2 * k] = i;
+  list[2 * k + 1] = block_bases[b] + local_offsets[i];
 }
 
 __global__ __launch_bounds__(1024) void mc_scan_blocks_kernel(unsigned long long* block_sums, size_t n_blocks,
                                                               unsigned long long* total)
 {
+  // (blockIdx.x == 1: the same over the live-tile sums, which follow the triangle sums; its total follows `total`)
+  block_sums += (size_t)blockIdx.x * n_blocks;
+  total += blockIdx.x;
   __shared__ unsigned long long wave_sum[16];
   __shared__ unsigned long long carry;
   const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
@@ -645,8 +689,16 @@ __global__ __launch_bounds__(256) void cloud_kernel(const CloudParams p, uint32_
 }
 }  // namespace
 
-static int tile_scratch(yakhip_ctx* ctx, size_t n_tiles, uint32_t** counts, uint32_t** local_offsets,
-                        unsigned long long** block_bases, unsigned long long** total, size_t* n_blocks_out);
+// scratch of the count -> scan -> emit passes (kept in the context, grown on demand)
+struct TileScratch
+{
+  uint32_t *counts, *local_offsets, *live_local;
+  unsigned long long *block_bases, *block_live;  // (block_live follows block_bases: mc_scan_blocks_kernel's second block)
+  unsigned long long* total;                     // [0] triangles / points, [1] live tiles
+  unsigned long long* list;                      // marching cubes: {tile, first slot} per live tile
+  size_t n_blocks;
+};
+static int tile_scratch(yakhip_ctx* ctx, size_t n_tiles, bool with_list, TileScratch* out);
 
 int launch_marching_cubes(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int z0, int layers, int min_weight,
                           double scale, float* triangles, unsigned long long capacity, unsigned long long* n_out,
@@ -680,11 +732,9 @@ int launch_marching_cubes(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, in
     return fail(YAKHIP_ERANGE, "marching_cubes: more than a million voxel rows");
   const size_t n_tiles = (size_t)p.nx * p.ny * p.nzs;
 
-  uint32_t *counts, *local_offsets;
-  unsigned long long *block_bases, *total;
-  size_t n_blocks;
+  TileScratch ts;
   {
-    const int rc = tile_scratch(ctx, n_tiles, &counts, &local_offsets, &block_bases, &total, &n_blocks);
+    const int rc = tile_scratch(ctx, n_tiles, true, &ts);
     if (rc != 0)
       return rc;
   }
@@ -692,43 +742,48 @@ int launch_marching_cubes(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, in
   const size_t wgs_layer = (size_t)p.nx * gy;
   if (wgs_layer * (size_t)p.nzs > 0x7fffffffull)
     return fail(YAKHIP_ERANGE, "marching_cubes: more than 2^31 workgroups");
-  const dim3 grid((unsigned)(wgs_layer * p.nzc)), grid_emit((unsigned)(wgs_layer * p.nzs));
+  const dim3 grid((unsigned)(wgs_layer * p.nzc));
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   int rc = timing_begin(ctx, &ev);  // one event pair around count + scan (+ the emit pass below gets its own)
   if (rc != 0)
     return rc;
-  hipLaunchKernelGGL((mc_kernel<false>), grid, dim3(256), 0, ctx->stream, p, counts, local_offsets, block_bases,
-                     (float*)nullptr);
+  hipLaunchKernelGGL((mc_kernel<false>), grid, dim3(256), 0, ctx->stream, p, ts.counts, (const unsigned long long*)nullptr,
+                     0ull, (float*)nullptr);
   YAKHIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(mc_scan_local_kernel, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, counts, local_offsets,
-                     n_tiles, block_bases);
-  hipLaunchKernelGGL(mc_scan_blocks_kernel, dim3(1), dim3(1024), 0, ctx->stream, block_bases, n_blocks, total);
+  hipLaunchKernelGGL(mc_scan_local_kernel, dim3((unsigned)ts.n_blocks), dim3(256), 0, ctx->stream, ts.counts, ts.local_offsets,
+                     n_tiles, ts.block_bases, ts.live_local, ts.block_live);
+  hipLaunchKernelGGL(mc_scan_blocks_kernel, dim3(2), dim3(1024), 0, ctx->stream, ts.block_bases, ts.n_blocks, ts.total);
+  // the tiles that hold triangles, in tile order, each with its first slot: the emit pass is launched over these alone
+  hipLaunchKernelGGL(mc_compact_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, ts.counts,
+                     ts.local_offsets, ts.block_bases, ts.live_local, ts.block_live, n_tiles, ts.list);
   if ((rc = timing_end(ctx, ev)) != 0)
     return rc;
   YAKHIP_TRY(hipGetLastError());
-  YAKHIP_TRY(hipMemcpyAsync(ctx->mc_pinned, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  YAKHIP_TRY(hipMemcpyAsync(ctx->mc_pinned, ts.total, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
-  const unsigned long long n = *(const unsigned long long*)ctx->mc_pinned;
+  const unsigned long long n = ((const unsigned long long*)ctx->mc_pinned)[0];
+  const unsigned long long n_live = ((const unsigned long long*)ctx->mc_pinned)[1];
   *n_out = n;
   if (!triangles || n == 0 || n > capacity)
     return 0;  // count only (or the caller's buffer is too small: it sees n > capacity)
 
   if ((rc = timing_begin(ctx, &ev)) != 0)
     return rc;
-  hipLaunchKernelGGL((mc_kernel<true>), grid_emit, dim3(256), 0, ctx->stream, p, counts, local_offsets, block_bases,
-                     triangles);
+  hipLaunchKernelGGL((mc_kernel<true>), dim3((unsigned)((n_live + 3) / 4)), dim3(256), 0, ctx->stream, p, ts.counts, ts.list,
+                     n_live, triangles);
   if ((rc = timing_end(ctx, ev)) != 0)
     return rc;
   YAKHIP_TRY(hipGetLastError());
   return check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
 }
-// scratch of the count -> scan -> emit passes: counts (u32) | local offsets (u32) | block bases (u64) | total
-static int tile_scratch(yakhip_ctx* ctx, size_t n_tiles, uint32_t** counts, uint32_t** local_offsets,
-                        unsigned long long** block_bases, unsigned long long** total, size_t* n_blocks_out)
+// counts (u32) | local offsets (u32) | live offsets (u32) | block bases (u64) | live block bases (u64) | totals (2 x u64) |
+// the live-tile list (2 x u64 per tile, marching cubes only)
+static int tile_scratch(yakhip_ctx* ctx, size_t n_tiles, bool with_list, TileScratch* out)
 {
   const size_t n_blocks = (n_tiles + kScanBlock - 1) / kScanBlock;
   const size_t counts_bytes = (n_tiles * sizeof(uint32_t) + 15) & ~(size_t)15;
-  const size_t need = 2 * counts_bytes + (n_blocks + 1) * sizeof(unsigned long long);
+  const size_t fixed = 3 * counts_bytes + (2 * n_blocks + 2) * sizeof(unsigned long long);
+  const size_t need = fixed + (with_list ? n_tiles * 2 * sizeof(unsigned long long) : 0);
   if (ctx->mc_scratch_bytes < need)
   {
     if (ctx->mc_scratch)
@@ -742,12 +797,16 @@ static int tile_scratch(yakhip_ctx* ctx, size_t n_tiles, uint32_t** counts, uint
     ctx->mc_scratch_bytes = need;
   }
   if (!ctx->mc_pinned)
-    YAKHIP_TRY(hipHostMalloc(&ctx->mc_pinned, sizeof(unsigned long long), hipHostMallocDefault));
-  *counts = (uint32_t*)ctx->mc_scratch;
-  *local_offsets = (uint32_t*)((uint8_t*)ctx->mc_scratch + counts_bytes);
-  *block_bases = (unsigned long long*)((uint8_t*)ctx->mc_scratch + 2 * counts_bytes);
-  *total = *block_bases + n_blocks;
-  *n_blocks_out = n_blocks;
+    YAKHIP_TRY(hipHostMalloc(&ctx->mc_pinned, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+  uint8_t* base = (uint8_t*)ctx->mc_scratch;
+  out->counts = (uint32_t*)base;
+  out->local_offsets = (uint32_t*)(base + counts_bytes);
+  out->live_local = (uint32_t*)(base + 2 * counts_bytes);
+  out->block_bases = (unsigned long long*)(base + 3 * counts_bytes);
+  out->block_live = out->block_bases + n_blocks;
+  out->total = out->block_live + n_blocks;
+  out->list = (unsigned long long*)(base + fixed);
+  out->n_blocks = n_blocks;
   return 0;
 }
 
@@ -785,7 +844,9 @@ int launch_extract_cloud(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int
   uint32_t *counts, *local_offsets;
   unsigned long long *block_bases, *total;
   size_t n_blocks;
-  int rc = tile_scratch(ctx, n_tiles, &counts, &local_offsets, &block_bases, &total, &n_blocks);
+  TileScratch ts;
+  int rc = tile_scratch(ctx, n_tiles, false, &ts);
+  counts = ts.counts, local_offsets = ts.local_offsets, block_bases = ts.block_bases, total = ts.total, n_blocks = ts.n_blocks;
   if (rc != 0)
     return rc;
 
@@ -796,7 +857,7 @@ int launch_extract_cloud(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int
                      local_offsets, block_bases, (float4*)nullptr);
   YAKHIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(mc_scan_local_kernel, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, counts, local_offsets,
-                     n_tiles, block_bases);
+                     n_tiles, block_bases, (uint32_t*)nullptr, (unsigned long long*)nullptr);
   hipLaunchKernelGGL(mc_scan_blocks_kernel, dim3(1), dim3(1024), 0, ctx->stream, block_bases, n_blocks, total);
   if ((rc = timing_end(ctx, ev)) != 0)
     return rc;
