@@ -518,11 +518,13 @@ int yakhip_marching_cubes_layers(yakhip_ctx* ctx, const yakhip_volume* vol, int 
 /* The exact part of MarchingCubesParameters::clean (yak/src/mc/marching_cubes.cpp:204-216: vtkCleanPolyData,
  * point merging on): corners of the triangle soup with the same three bit patterns become one vertex.
  * triangles_dev: n_triangles * 9 floats as yakhip_marching_cubes writes them.  vertices_dev (3 floats per
- * vertex, room for 3 * n_triangles of them) receives the distinct points in ascending order of their
- * (x, y, z) bit patterns read as unsigned integers; index_dev (one uint32 per corner, 3 * n_triangles)
+ * vertex, room for 3 * n_triangles of them) receives the distinct points in the order of their first appearance
+ * in the triangle list (the order the reference's incremental point locator numbers them in; deterministic:
+ * yakhip_marching_cubes fixes every triangle's slot); index_dev (one uint32 per corner, 3 * n_triangles)
  * receives each corner's vertex.  Dropping triangles that repeat an index is left to the caller (one linear
- * pass).  Both output buffers 4-byte aligned.  BLOCKING; allocates and frees its scratch (about 20 bytes per
- * corner) inside the call.  At most 2^31 / 3 triangles. */
+ * pass).  Both output buffers 4-byte aligned.  BLOCKING; its scratch (about 20 bytes per corner) is kept in the
+ * context and grows with the largest call.  At most 2^30 / 3 triangles.  (Until round 3 the points came out in
+ * ascending order of their bit patterns, which cost three sorts.) */
 int yakhip_weld_vertices(yakhip_ctx* ctx, const void* triangles_dev, unsigned long long n_triangles, void* vertices_dev,
                          void* index_dev, unsigned long long* n_vertices_host);
 

@@ -174,16 +174,20 @@ def test_mc_512_volume_fused_on_gpu(gpu_ctx):
 # ---- yakhip_weld_vertices: the exact point merging of MarchingCubesParameters::clean ---------------------------
 
 def numpy_weld(tris):
-    """Distinct corners in ascending (x, y, z) bit-pattern order, and every corner's vertex number."""
+    """Distinct corners in the order of their first appearance in the list, and every corner's vertex number
+    (include/yakhip.h: yakhip_weld_vertices)."""
     bits = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 3).view(np.uint32)
-    order = np.lexsort((bits[:, 2], bits[:, 1], bits[:, 0]))
+    order = np.lexsort((bits[:, 2], bits[:, 1], bits[:, 0]))  # stable: equal points stay in list order
     s = bits[order]
     head = np.ones(len(s), dtype=bool)
     head[1:] = (s[1:] != s[:-1]).any(axis=1)
-    ids = np.cumsum(head) - 1
+    group = np.cumsum(head) - 1                                # group of each sorted place
+    first = order[head]                                        # first list position of every group
+    rank = np.empty(len(first), dtype=np.int64)
+    rank[np.argsort(first, kind="stable")] = np.arange(len(first))
     index = np.empty(len(s), dtype=np.uint32)
-    index[order] = ids
-    return s[head], index
+    index[order] = rank[group]
+    return bits[np.sort(first)], index
 
 
 def gpu_weld(ctx, tris):
@@ -203,7 +207,10 @@ def test_weld_dipyramid(gpu_ctx):
     tris = gpu_mc(gpu_ctx, torch.from_numpy(vol.view(np.int32)).cuda(), (3, 3, 3), 1, 0.01)
     verts, index = gpu_weld(gpu_ctx, tris)
     assert len(verts) == 6                                                # test/marching_cubes_tests.cpp:133
-    assert np.array_equal(verts.view(np.float32), DIPYRAMID_VERTICES[np.lexsort(DIPYRAMID_VERTICES.T[::-1])])
+    assert np.array_equal(verts[np.lexsort(verts.T[::-1])].view(np.float32),
+                          DIPYRAMID_VERTICES[np.lexsort(DIPYRAMID_VERTICES.view(np.uint32).T[::-1])])
+    want_v, want_i = numpy_weld(tris)
+    assert np.array_equal(verts, want_v) and np.array_equal(index, want_i)
     faces = index.reshape(-1, 3)
     assert len(faces) == 8 and (faces[:, 0] != faces[:, 1]).all() and (faces[:, 1] != faces[:, 2]).all()
     # every corner got the vertex with its own bits

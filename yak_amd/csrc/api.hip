@@ -183,6 +183,8 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->prepared_next = 0;
   ctx->mc_scratch = nullptr;
   ctx->mc_scratch_bytes = 0;
+  ctx->weld_scratch = nullptr;
+  ctx->weld_scratch_bytes = 0;
   ctx->mc_pinned = nullptr;
   ctx->stage[0] = ctx->stage[1] = nullptr;
   ctx->stage_done[0] = ctx->stage_done[1] = nullptr;
@@ -253,6 +255,8 @@ int yakhip_ctx_destroy(yakhip_ctx* ctx)
       (void)hipHostFree(ctx->icp_pinned);
     if (ctx->mc_scratch)
       (void)hipFree(ctx->mc_scratch);
+    if (ctx->weld_scratch)
+      (void)hipFree(ctx->weld_scratch);
     if (ctx->mc_pinned)
       (void)hipHostFree(ctx->mc_pinned);
     for (int i = 0; i < 2; ++i)
@@ -1833,7 +1837,7 @@ int yakhip_weld_vertices(yakhip_ctx* ctx, const void* triangles_dev, unsigned lo
     return fail(YAKHIP_EINVAL, "weld_vertices: null buffer");
   if ((uintptr_t)triangles_dev % 4 != 0 || (uintptr_t)vertices_dev % 4 != 0 || (uintptr_t)index_dev % 4 != 0)
     return fail(YAKHIP_EALIGN, "weld_vertices: buffers must be 4-byte aligned");
-  if (n_triangles > 0x7fffffffull / 3ull)
+  if (n_triangles > 0x3fffffffull / 3ull)
     return fail(YAKHIP_ERANGE, "weld_vertices: %llu triangles, at most %llu", n_triangles, 0x7fffffffull / 3ull);
   return launch_weld(ctx, (const uint32_t*)triangles_dev, (uint32_t)(n_triangles * 3ull), (uint32_t*)vertices_dev,
                      (uint32_t*)index_dev, n_vertices_host);

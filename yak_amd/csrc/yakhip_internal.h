@@ -75,6 +75,8 @@ struct yakhip_ctx
   int icp_poll;        // the host polls that ticket (default) / copies and synchronises
   void* mc_scratch;    // marching cubes: tile counts, tile offsets, total (device)
   size_t mc_scratch_bytes;
+  void* weld_scratch;  // yakhip_weld_vertices: hash table, per-corner slots, sort arrays (device; grown on demand)
+  size_t weld_scratch_bytes;
   void* mc_pinned;     // marching cubes: pinned host copy of the total
   void* stage[2];      // host <-> device copies: two pinned staging buffers and the events that free them
   hipEvent_t stage_done[2];

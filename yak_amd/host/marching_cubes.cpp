@@ -63,9 +63,10 @@ PolygonMesh marchingCubesDevice(const void* volume_dev, int dim_x, int dim_y, in
     return mesh;
   }
 
-  // :204-216 -- exact point merging (bit patterns) on the device: distinct points in ascending order of their
-  // bit patterns and every corner's point (yakhip_weld_vertices: three radix-sort passes instead of the 120 ms
-  // a four-thread host sort of 2.4 M corners took); then triangles with a repeated index are dropped.
+  // :204-216 -- exact point merging (bit patterns) on the device: distinct points in the order of their first
+  // appearance in the triangle list, as vtkCleanPolyData's point locator numbers them, and every corner's point
+  // (yakhip_weld_vertices: a hash table and a scan instead of the 120 ms a four-thread host sort of 2.4 M corners
+  // took); then triangles with a repeated index are dropped.
   const size_t corners = (size_t)n * 3;
   kfusion::cuda::DeviceMemory verts(corners * 3 * sizeof(float)), index_dev(corners * sizeof(std::uint32_t));
   unsigned long long nv = 0;
