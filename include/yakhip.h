@@ -373,9 +373,11 @@ int yakhip_comm_allreduce(yakhip_ctx* ctx, yakhip_comm* comm, void* buf_dev, siz
  * yakhip_raycast_resolve, and the composite of the few pixels that call settled (one more all-reduce over a list
  * of fixed capacity).  Arguments as yakhip_raycast_slab; on return (stream-ordered, not waited for) points /
  * depth / normals hold, on EVERY rank, what yakhip_raycast_points / _depth give on the whole volume, bit for
- * bit, and keys the composited keys.  Per call: 3 collectives -- 4 B, then 28 B per pixel, then 32 B per list
- * slot (capacity max(4096, pixels / 64); yakhip_comm_status reports a frame that needed more).
- * The communicator owns the scratch (about 40 B per pixel), allocated on first use. */
+ * bit, and keys the composited keys.  Per call: 3 collectives -- 4 B per pixel (the keys), then 16 B per pixel (the
+ * winner's march time and normal: every rank rebuilds the vertex and the depth from the time with the ray cast's own
+ * arithmetic; 28 B until round 3), then 16 B per list slot (capacity max(4096, pixels / 64); yakhip_comm_status
+ * reports a frame that needed more).  At 640 x 480: 1.2 MB + 4.9 MB + 77 KB per rank and frame.
+ * The communicator owns the scratch (about 32 B per pixel), allocated on first use. */
 int yakhip_raycast_sharded(yakhip_ctx* ctx, yakhip_comm* comm, const yakhip_volume* vol, int z_own0, int z_own1,
                            const float R[9], const float t[3], const float Rinv[9], const float intr[4],
                            float step_factor, float gradient_delta_factor, void* points_dev, size_t points_pitch,

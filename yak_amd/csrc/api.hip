@@ -184,6 +184,7 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->mc_scratch = nullptr;
   ctx->mc_scratch_bytes = 0;
   ctx->weld_scratch = nullptr;
+  ctx->icp_sums = nullptr;
   ctx->weld_scratch_bytes = 0;
   ctx->mc_pinned = nullptr;
   ctx->stage[0] = ctx->stage[1] = nullptr;
@@ -251,6 +252,8 @@ int yakhip_ctx_destroy(yakhip_ctx* ctx)
         (void)hipEventDestroy(ctx->thr_read[i]);
     if (ctx->icp_scratch)
       (void)hipFree(ctx->icp_scratch);
+    if (ctx->icp_sums)
+      (void)hipFree(ctx->icp_sums);
     if (ctx->icp_pinned)
       (void)hipHostFree(ctx->icp_pinned);
     if (ctx->mc_scratch)
@@ -1076,7 +1079,8 @@ static int raycast_common(yakhip_ctx* ctx, const yakhip_volume* vol, const float
                           const float Rinv[9], const float intr[4], float step_factor, float gradient_delta_factor,
                           void* points, size_t points_pitch, void* depth, size_t depth_pitch, void* normals,
                           size_t normals_pitch, int rows, int cols, void* keys = nullptr, size_t keys_pitch = 0,
-                          int z_own0 = 0, int z_own1 = 0, const RaycastPyramid* pyr = nullptr)
+                          int z_own0 = 0, int z_own1 = 0, const RaycastPyramid* pyr = nullptr, int32_t* key_out = nullptr,
+                          float* ts_out = nullptr, RaycastParams* params_out = nullptr)
 {
   int rc = enter(ctx);
   if (rc != 0)
@@ -1150,6 +1154,7 @@ static int raycast_common(yakhip_ctx* ctx, const yakhip_volume* vol, const float
   }
   p.keys = (uint8_t*)keys, p.keys_pitch = (uint32_t)keys_pitch;
   p.z_base = vol->z0, p.z_held = vol->z1 - vol->z0, p.z_own0 = z_own0, p.z_own1 = z_own1;
+  p.key_out = key_out, p.ts_out = ts_out;
   p.skip = (const uint32_t*)vol->surface_map;
   p.skip_x = (vol->dims[0] + 15) >> 4, p.skip_y = (vol->dims[1] + 15) >> 4;
   const size_t words = surface_brick_words(vol->dims[0], vol->dims[1], vol->z1 - vol->z0);
@@ -1171,6 +1176,8 @@ static int raycast_common(yakhip_ctx* ctx, const yakhip_volume* vol, const float
                   steps * 0x1p-23f * time_reach < 0.25f * p.time_step;
   }
   p.vol_bytes = (unsigned long long)vol->dims[0] * (unsigned long long)vol->dims[1] * (unsigned long long)(vol->z1 - vol->z0) * 4ull;
+  if (params_out)
+    *params_out = p;
   return launch_raycast(ctx, p);
 }
 
@@ -1708,8 +1715,9 @@ int yakhip_icp_estimate_sharded(yakhip_ctx* ctx, yakhip_comm* comm, const float 
   // their all-reduce, a wait, and the reference's host-side determinant test and SVD solve.
   int rank = 0, world = 1;
   yakhip_comm_info(comm, &rank, &world);
-  float* sums_dev = nullptr;
-  YAKHIP_TRY(hipMalloc((void**)&sums_dev, 33 * sizeof(float)));
+  if (!ctx->icp_sums)  // (kept in the context: this path runs once per frame for as long as a frame needs it)
+    YAKHIP_TRY(hipMalloc((void**)&ctx->icp_sums, 64 * sizeof(float)));
+  float* sums_dev = ctx->icp_sums;
   float Rc[9], tc[3], host[33];
   memcpy(Rc, R, sizeof(Rc));
   memcpy(tc, t, sizeof(tc));
@@ -1735,7 +1743,6 @@ int yakhip_icp_estimate_sharded(yakhip_ctx* ctx, yakhip_comm* comm, const float 
       }
     }
   }
-  (void)hipFree(sums_dev);
   memcpy(R_out, Rc, sizeof(Rc));
   memcpy(t_out, tc, sizeof(tc));
   return rc;
@@ -1749,20 +1756,31 @@ int yakhip_raycast_sharded(yakhip_ctx* ctx, yakhip_comm* comm, const yakhip_volu
 {
   if (!comm)
     return fail(YAKHIP_EINVAL, "raycast_sharded: null communicator");
-  int rc = yakhip_raycast_slab(ctx, vol, z_own0, z_own1, R, t, Rinv, intr, step_factor, gradient_delta_factor, points_dev,
-                               points_pitch, depth_dev, depth_pitch, normals_dev, normals_pitch, keys_dev, keys_pitch, rows,
-                               cols);
+  if (!keys_dev)
+    return fail(YAKHIP_EINVAL, "raycast_sharded: null keys image");
+  if (rows < 1 || cols < 1 || (long long)rows * cols > 0x7fffffffll / 32)
+    return fail(YAKHIP_ERANGE, "raycast_sharded: image of %d x %d pixels", cols, rows);
+  int rc = enter(ctx);
   if (rc != 0)
     return rc;
-  if ((long long)rows * cols > 0x7fffffffll / 32)
-    return fail(YAKHIP_ERANGE, "raycast_sharded: image too large");
+  // the slab's ray cast leaves, beside its images, every pixel's key and march time in the communicator's scratch:
+  // that is what the composite exchanges (comm.hip)
+  int32_t* keys_flat = nullptr;
+  float* ts_flat = nullptr;
+  if ((rc = composite_buffers(ctx, comm, rows * cols, ctx->composite_capacity, &keys_flat, &ts_flat)) != 0)
+    return rc;
+  RaycastParams rp;
+  if ((rc = raycast_common(ctx, vol, R, t, Rinv, intr, step_factor, gradient_delta_factor, points_dev, points_pitch, depth_dev,
+                           depth_pitch, normals_dev, normals_pitch, rows, cols, keys_dev, keys_pitch, z_own0, z_own1, nullptr,
+                           keys_flat, ts_flat, &rp)) != 0)
+    return rc;
   CompositeImages im;
   im.points = (uint8_t*)points_dev, im.normals = (uint8_t*)normals_dev, im.depth = (uint8_t*)depth_dev;
   im.keys = (uint8_t*)keys_dev;
   im.points_pitch = (uint32_t)points_pitch, im.normals_pitch = (uint32_t)normals_pitch;
   im.depth_pitch = (uint32_t)depth_pitch, im.keys_pitch = (uint32_t)keys_pitch;
   im.rows = rows, im.cols = cols;
-  if ((rc = composite_first(ctx, comm, im, ctx->composite_capacity)) != 0)
+  if ((rc = composite_first(ctx, comm, rp, ctx->composite_capacity)) != 0)
     return rc;
   if ((rc = yakhip_raycast_resolve(ctx, vol, z_own0, z_own1, Rinv, gradient_delta_factor, points_dev, points_pitch,
                                    depth_dev, depth_pitch, normals_dev, normals_pitch, keys_dev, keys_pitch, rows, cols)) != 0)

@@ -208,73 +208,41 @@ int comm_world(const yakhip_comm* c) { return c->world; }
 // the pixels whose best key is odd -- the same list, in the same order, on every rank -- are composited once
 // more; exactly one rank (the one whose layers hold the refined point) has turned such a key even.
 constexpr int kKeyNone = 0x7fffffff;
-constexpr int kPayloadWords = 7;  // vertex xyz, normal xyz, depth
+// What a winner ships (round 3; seven words until then: vertex, normal, depth): the march time of its refined point and
+// the normal.  Every rank rebuilds the point, the vertex and the depth from the time with the ray cast's own
+// instructions (raycast.hip: composite_unpack_kernel).
+constexpr int kPayloadWords = 4;
 
 __device__ __forceinline__ int32_t* key_at(const CompositeImages& im, int y, int x)
 {
   return (int32_t*)(im.keys + (size_t)y * im.keys_pitch) + x;
 }
 
-// the fourth lane of a map pixel: 0 beside a value, the NaN itself beside a NaN (the kernels write all four lanes
-// of a pixel without a result as quiet NaN, tsdf_volume.cu:298)
-__device__ __forceinline__ uint32_t lane_w(uint32_t x) { return (x & 0x7fffffffu) > 0x7f800000u ? x : 0u; }
-
-__global__ __launch_bounds__(256) void pack_keys_kernel(CompositeImages im, int32_t* best)
+// payload words of pixel i, zeroed unless this rank holds the best key.  keys (image) / ts: what this rank's slab ray
+// cast left per pixel; best: the keys after the MIN over the ranks (the ray cast wrote this rank's into it: no packing pass).
+__global__ __launch_bounds__(256) void mask_pack_kernel(const uint8_t* normals, uint32_t normals_pitch, const uint8_t* keys,
+                                                        uint32_t keys_pitch, int rows, int cols, const float* ts,
+                                                        const int32_t* best, uint32_t* packed)
 {
   const int i = (int)(blockIdx.x * 256u + threadIdx.x);
-  if (i < im.rows * im.cols)
-    best[i] = *key_at(im, i / im.cols, i % im.cols);
-}
-
-// payload words of pixel i, zeroed unless this rank holds the best key
-__global__ __launch_bounds__(256) void mask_pack_kernel(CompositeImages im, const int32_t* best, uint32_t* packed)
-{
-  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
-  const int n = im.rows * im.cols;
+  const int n = rows * cols;
   if (i >= n)
     return;
-  const int y = i / im.cols, x = i % im.cols;
+  const int y = i / cols, x = i % cols;
   const int32_t b = best[i];
-  const bool mine = b != kKeyNone && *key_at(im, y, x) == b;
-  uint32_t w[kPayloadWords] = { 0, 0, 0, 0, 0, 0, 0 };
-  if (mine)
+  uint32_t w[kPayloadWords] = { 0, 0, 0, 0 };
+  if (b != kKeyNone && ((const int32_t*)(keys + (size_t)y * keys_pitch))[x] == b)
   {
-    if (im.points)
+    w[0] = __builtin_bit_cast(uint32_t, ts[i]);
+    if ((b & 1) == 0)  // (an odd key: the normals image holds the point, which the time gives as well)
     {
-      const uint4 p = ((const uint4*)(im.points + (size_t)y * im.points_pitch))[x];
-      w[0] = p.x, w[1] = p.y, w[2] = p.z;
+      const uint4 q = ((const uint4*)(normals + (size_t)y * normals_pitch))[x];
+      w[1] = q.x, w[2] = q.y, w[3] = q.z;
     }
-    const uint4 q = ((const uint4*)(im.normals + (size_t)y * im.normals_pitch))[x];
-    w[3] = q.x, w[4] = q.y, w[5] = q.z;
-    if (im.depth)
-      w[6] = ((const uint16_t*)(im.depth + (size_t)y * im.depth_pitch))[x];
   }
 #pragma unroll
   for (int k = 0; k < kPayloadWords; ++k)
     packed[(size_t)k * n + i] = w[k];
-}
-
-// the composited pixel back into the images (NaN / 0 where no slab's march ended), keys <- best
-__global__ __launch_bounds__(256) void unpack_kernel(CompositeImages im, const int32_t* best, const uint32_t* packed)
-{
-  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
-  const int n = im.rows * im.cols;
-  if (i >= n)
-    return;
-  const int y = i / im.cols, x = i % im.cols;
-  const int32_t b = best[i];
-  const uint32_t qnan = 0x7fc00000u;
-  uint32_t w[kPayloadWords];
-#pragma unroll
-  for (int k = 0; k < kPayloadWords; ++k)
-    w[k] = packed[(size_t)k * n + i];
-  const bool none = b == kKeyNone;
-  if (im.points)
-    ((uint4*)(im.points + (size_t)y * im.points_pitch))[x] = none ? uint4{ qnan, qnan, qnan, qnan } : uint4{ w[0], w[1], w[2], lane_w(w[0]) };
-  ((uint4*)(im.normals + (size_t)y * im.normals_pitch))[x] = none ? uint4{ qnan, qnan, qnan, qnan } : uint4{ w[3], w[4], w[5], lane_w(w[3]) };
-  if (im.depth)
-    ((uint16_t*)(im.depth + (size_t)y * im.depth_pitch))[x] = none ? (uint16_t)0 : (uint16_t)w[6];
-  *key_at(im, y, x) = b;
 }
 
 struct OddKey
@@ -283,7 +251,10 @@ struct OddKey
   __device__ bool operator()(int i) const { return best[i] != kKeyNone && (best[i] & 1); }
 };
 
-// deferred pixels after the resolve: entry j = {changed, payload} of list[j], zeros beyond the list
+// deferred pixels after the resolve: entry j = {outcome, normal} of list[j], zeros beyond the list and on the ranks that
+// did not settle the pixel.  outcome 1: the normal; 2: the normal came out NaN and the hit is discarded
+// (tsdf_volume.cu:340-348) -- vertex and depth, which every rank holds since the first step, then go too.
+constexpr int kEntryWords = 4;
 __global__ __launch_bounds__(256) void gather_deferred_kernel(CompositeImages im, const int32_t* best, const int* list,
                                                                const unsigned* count, int cap, uint32_t* entries,
                                                                unsigned* overflow)
@@ -293,27 +264,22 @@ __global__ __launch_bounds__(256) void gather_deferred_kernel(CompositeImages im
     atomicAdd(overflow, 1u);
   if (j >= cap)
     return;
-  uint32_t w[kPayloadWords + 1] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  uint32_t w[kEntryWords] = { 0, 0, 0, 0 };
   if ((unsigned)j < *count)
   {
     const int i = list[j], y = i / im.cols, x = i % im.cols;
     const int32_t k = *key_at(im, y, x);
     if ((k & 1) == 0 && k == best[i] - 1)  // this rank's resolve settled the pixel
     {
-      w[0] = 1u;
-      if (im.points)
-      {
-        const uint4 p = ((const uint4*)(im.points + (size_t)y * im.points_pitch))[x];
-        w[1] = p.x, w[2] = p.y, w[3] = p.z;
-      }
       const uint4 q = ((const uint4*)(im.normals + (size_t)y * im.normals_pitch))[x];
-      w[4] = q.x, w[5] = q.y, w[6] = q.z;
-      if (im.depth)
-        w[7] = ((const uint16_t*)(im.depth + (size_t)y * im.depth_pitch))[x];
+      const bool discarded = (q.x & 0x7fffffffu) > 0x7f800000u;
+      w[0] = discarded ? 2u : 1u;
+      if (!discarded)
+        w[1] = q.x, w[2] = q.y, w[3] = q.z;
     }
   }
 #pragma unroll
-  for (int k = 0; k < kPayloadWords + 1; ++k)
+  for (int k = 0; k < kEntryWords; ++k)
     entries[(size_t)k * cap + j] = w[k];
 }
 
@@ -323,18 +289,22 @@ __global__ __launch_bounds__(256) void scatter_deferred_kernel(CompositeImages i
   const int j = (int)(blockIdx.x * 256u + threadIdx.x);
   if (j >= cap || (unsigned)j >= *count)
     return;
-  if (entries[j] == 0u)
+  const uint32_t outcome = entries[j];
+  if (outcome == 0u)
     return;  // no slab holds the refined point (it left the volume): the pixel stays as the first step left it
   const int i = list[j], y = i / im.cols, x = i % im.cols;
-  if (im.points)
-    ((uint4*)(im.points + (size_t)y * im.points_pitch))[x] =
-        uint4{ entries[(size_t)1 * cap + j], entries[(size_t)2 * cap + j], entries[(size_t)3 * cap + j],
-               lane_w(entries[(size_t)1 * cap + j]) };
-  ((uint4*)(im.normals + (size_t)y * im.normals_pitch))[x] =
-      uint4{ entries[(size_t)4 * cap + j], entries[(size_t)5 * cap + j], entries[(size_t)6 * cap + j],
-             lane_w(entries[(size_t)4 * cap + j]) };
-  if (im.depth)
-    ((uint16_t*)(im.depth + (size_t)y * im.depth_pitch))[x] = (uint16_t)entries[(size_t)7 * cap + j];
+  const uint32_t qnan = 0x7fc00000u;
+  if (outcome == 1u)
+    ((uint4*)(im.normals + (size_t)y * im.normals_pitch))[x] =
+        uint4{ entries[(size_t)1 * cap + j], entries[(size_t)2 * cap + j], entries[(size_t)3 * cap + j], 0u };
+  else
+  {
+    ((uint4*)(im.normals + (size_t)y * im.normals_pitch))[x] = uint4{ qnan, qnan, qnan, qnan };
+    if (im.points)
+      ((uint4*)(im.points + (size_t)y * im.points_pitch))[x] = uint4{ qnan, qnan, qnan, qnan };
+    if (im.depth)
+      ((uint16_t*)(im.depth + (size_t)y * im.depth_pitch))[x] = (uint16_t)0;
+  }
   *key_at(im, y, x) = best[i] - 1;
 }
 
@@ -343,7 +313,9 @@ __global__ __launch_bounds__(256) void scatter_deferred_kernel(CompositeImages i
 
 struct CompositeScratch
 {
-  int32_t* best;
+  int32_t* best;       // the keys: this rank's own after the slab ray cast (RaycastParams::key_out), the smallest over the
+                       // ranks after the MIN (the keys image keeps this rank's own until the composite is done)
+  float* ts;           // this rank's march times (RaycastParams::ts_out)
   uint32_t* packed;
   int* list;
   unsigned* count;     // [0] list length, [1] overflow events (accumulated until read)
@@ -363,8 +335,8 @@ static int composite_scratch(yakhip_ctx* ctx, yakhip_comm* comm, int n, int cap_
   YAKHIP_TRY(rocprim::select(nullptr, select_bytes, rocprim::counting_iterator<int>(0), (int*)nullptr, (unsigned*)nullptr,
                              (size_t)n, pred, ctx->stream));
   auto up = [](size_t v) { return (v + 255u) & ~(size_t)255u; };
-  const size_t need = up((size_t)n * 4u) + up((size_t)n * 4u * kPayloadWords) + up((size_t)n * 4u) + 256u +
-                      up((size_t)s.cap * 4u * (kPayloadWords + 1)) + up(select_bytes);
+  const size_t need = 256u + 2 * up((size_t)n * 4u) + up((size_t)n * 4u * kPayloadWords) + up((size_t)n * 4u) +
+                      up((size_t)s.cap * 4u * kEntryWords) + up(select_bytes);
   if (comm->scratch_bytes < need)
   {
     if (comm->scratch)
@@ -381,29 +353,44 @@ static int composite_scratch(yakhip_ctx* ctx, yakhip_comm* comm, int n, int cap_
   char* p = (char*)comm->scratch;
   s.count = (unsigned*)p, p += 256;
   s.best = (int32_t*)p, p += up((size_t)n * 4u);
+  s.ts = (float*)p, p += up((size_t)n * 4u);
   s.packed = (uint32_t*)p, p += up((size_t)n * 4u * kPayloadWords);
   s.list = (int*)p, p += up((size_t)n * 4u);
-  s.entries = (uint32_t*)p, p += up((size_t)s.cap * 4u * (kPayloadWords + 1));
+  s.entries = (uint32_t*)p, p += up((size_t)s.cap * 4u * kEntryWords);
   s.select_temp = p;
   s.select_bytes = select_bytes;
   return 0;
 }
 
-int composite_first(yakhip_ctx* ctx, yakhip_comm* comm, const CompositeImages& im, int cap_request)
+int composite_buffers(yakhip_ctx* ctx, yakhip_comm* comm, int n, int cap_request, int32_t** keys_flat, float** ts_flat)
 {
-  const int n = im.rows * im.cols;
+  CompositeScratch s;
+  const int rc = composite_scratch(ctx, comm, n, cap_request, s);
+  if (rc != 0)
+    return rc;
+  *keys_flat = s.best, *ts_flat = s.ts;
+  return 0;
+}
+
+// rp: the parameters the slab ray cast of this frame ran with (its key_out / ts_out are composite_buffers' arrays)
+int composite_first(yakhip_ctx* ctx, yakhip_comm* comm, const RaycastParams& rp, int cap_request)
+{
+  const int n = rp.rows * rp.cols;
   CompositeScratch s;
   int rc = composite_scratch(ctx, comm, n, cap_request, s);
   if (rc != 0)
     return rc;
+  if (rp.key_out != s.best || rp.ts_out != s.ts)
+    return fail(YAKHIP_EINVAL, "composite: the slab ray cast did not write into the communicator's buffers");
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(pack_keys_kernel, dim3(blocks), dim3(256), 0, ctx->stream, im, s.best);
   if ((rc = comm_allreduce(ctx, comm, s.best, (size_t)n, YAKHIP_MIN_I32)) != 0)
     return rc;
-  hipLaunchKernelGGL(mask_pack_kernel, dim3(blocks), dim3(256), 0, ctx->stream, im, s.best, s.packed);
+  hipLaunchKernelGGL(mask_pack_kernel, dim3(blocks), dim3(256), 0, ctx->stream, rp.normals, rp.normals_pitch, rp.keys,
+                     rp.keys_pitch, rp.rows, rp.cols, s.ts, s.best, s.packed);
   if ((rc = comm_allreduce(ctx, comm, s.packed, (size_t)n * kPayloadWords, YAKHIP_SUM_I32)) != 0)
     return rc;
-  hipLaunchKernelGGL(unpack_kernel, dim3(blocks), dim3(256), 0, ctx->stream, im, s.best, s.packed);
+  if ((rc = launch_composite_unpack(ctx, rp, s.best, s.packed)) != 0)
+    return rc;
   // the pixels still to be resolved, in pixel order (the same list on every rank)
   OddKey pred{ s.best };
   size_t bytes = s.select_bytes;
@@ -422,7 +409,7 @@ int composite_second(yakhip_ctx* ctx, yakhip_comm* comm, const CompositeImages& 
   const unsigned blocks = (unsigned)((s.cap + 255) / 256);
   hipLaunchKernelGGL(gather_deferred_kernel, dim3(blocks), dim3(256), 0, ctx->stream, im, s.best, s.list, s.count, s.cap,
                      s.entries, s.count + 1);
-  if ((rc = comm_allreduce(ctx, comm, s.entries, (size_t)s.cap * (kPayloadWords + 1), YAKHIP_SUM_I32)) != 0)
+  if ((rc = comm_allreduce(ctx, comm, s.entries, (size_t)s.cap * kEntryWords, YAKHIP_SUM_I32)) != 0)
     return rc;
   hipLaunchKernelGGL(scatter_deferred_kernel, dim3(blocks), dim3(256), 0, ctx->stream, im, s.best, s.list, s.count, s.cap,
                      s.entries);

@@ -236,6 +236,35 @@ __device__ __forceinline__ void average_block(int lane, int right, int down, flo
 // replays the march's arithmetic up to its first pair without fetching anything, examines its own pairs as the
 // whole march would have, and the smallest pair index that ends the march wins (tsdf_volume.cu:320-351 stops at the
 // first such pair): same image, the longest ray costs a SEG-th.  The workgroup then covers 4 / SEG tiles of 8 x 8.
+// tsdf_volume.cu:300-301; device.hpp:57-62 with z = 1: the direction of pixel (x, y)'s ray in the volume frame
+// (one function for the ray cast and for the composite that rebuilds vertices from march times: the same instructions)
+__device__ __forceinline__ void pixel_ray(const RaycastParams& p, int x, int y, float& dx, float& dy, float& dz)
+{
+  const float rx = ((float)x - p.cx) * p.finvx;
+  const float ry = ((float)y - p.cy) * p.finvy;
+  dx = dot3(p.R[0], p.R[1], p.R[2], rx, ry, 1.f);
+  dy = dot3(p.R[3], p.R[4], p.R[5], rx, ry, 1.f);
+  dz = dot3(p.R[6], p.R[7], p.R[8], rx, ry, 1.f);
+  normalize3(dx, dy, dz);
+}
+
+// the vertex (camera frame) of the point at march time Ts on that ray, and its depth in millimetres: tsdf_volume.cu:338,
+// 346 / 279-280 as raycast_kernel states them
+__device__ __forceinline__ void ray_vertex(const RaycastParams& p, float dx, float dy, float dz, float Ts, float& px, float& py,
+                                           float& pz, float& vx, float& vy, float& vz)
+{
+  px = p.t[0] + dx * Ts, py = p.t[1] + dy * Ts, pz = p.t[2] + dz * Ts;
+  const float wx = px - p.t[0], wy = py - p.t[1], wz = pz - p.t[2];
+  vx = dot3(p.Rinv[0], p.Rinv[1], p.Rinv[2], wx, wy, wz);
+  vy = dot3(p.Rinv[3], p.Rinv[4], p.Rinv[5], wx, wy, wz);
+  vz = dot3(p.Rinv[6], p.Rinv[7], p.Rinv[8], wx, wy, wz);
+}
+__device__ __forceinline__ unsigned short vertex_depth_mm(float vz)
+{  // static_cast<ushort>(vertex.z * 1000): truncating, saturating conversion
+  const float mm = vz * 1000.f;
+  return (unsigned short)(mm >= 65535.f ? 65535 : (mm > 0.f ? (int)mm : 0));
+}
+
 template <bool IDX32, bool SLAB, bool SKIP, int SEG>
 __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, int tiles_x, int n_tiles, int per_xcd)
 {
@@ -279,13 +308,8 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
 
   RC_CLOCK(rc_t1);
   RC_CLOCK(rc_t2);
-  // tsdf_volume.cu:300-301; device.hpp:57-62 with z = 1
-  const float rx = ((float)x - p.cx) * p.finvx;
-  const float ry = ((float)y - p.cy) * p.finvy;
-  float dx = dot3(p.R[0], p.R[1], p.R[2], rx, ry, 1.f);
-  float dy = dot3(p.R[3], p.R[4], p.R[5], rx, ry, 1.f);
-  float dz = dot3(p.R[6], p.R[7], p.R[8], rx, ry, 1.f);
-  normalize3(dx, dy, dz);
+  float dx, dy, dz;
+  pixel_ray(p, x, y, dx, dy, dz);
   const float ox = p.t[0], oy = p.t[1], oz = p.t[2];
 
   // tsdf_volume.cu:149-165, 306-314
@@ -658,6 +682,7 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
   const float qnan = __builtin_nanf("");
   float vx = qnan, vy = qnan, vz = qnan, vw = qnan, n0 = qnan, n1 = qnan, n2 = qnan, n3 = qnan;
   bool hit = false, deferred = false;
+  float ts_hit = qnan;  // the march time of the refined point, for the composite over slabs
   bool winner = true;
   if constexpr (SEG > 1)
   {
@@ -675,7 +700,8 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
     const float Ft = interpolate<IDX32, SLAB>(p, hcx * p.ivx, hcy * p.ivy, hcz * p.ivz, held_bracket);
     const float Ftdt = interpolate<IDX32, SLAB>(p, hnx * p.ivx, hny * p.ivy, hnz * p.ivz, held_bracket);
     const float Ts = tcurr - (ts * Ft) / (Ftdt - Ft);
-    const float px = ox + dx * Ts, py = oy + dy * Ts, pz = oz + dz * Ts;
+    float px, py, pz, hx, hy, hz;
+    ray_vertex(p, dx, dy, dz, Ts, px, py, pz, hx, hy, hz);
     float gx, gy, gz;
     surface_gradient<IDX32, SLAB>(p, px, py, pz, gx, gy, gz, held_normal);
     const float prod = gx * gy * gz;
@@ -683,10 +709,8 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
     if (deferred || !(prod != prod))
     {
       hit = true;
-      const float wx = px - p.t[0], wy = py - p.t[1], wz = pz - p.t[2];
-      vx = dot3(p.Rinv[0], p.Rinv[1], p.Rinv[2], wx, wy, wz);
-      vy = dot3(p.Rinv[3], p.Rinv[4], p.Rinv[5], wx, wy, wz);
-      vz = dot3(p.Rinv[6], p.Rinv[7], p.Rinv[8], wx, wy, wz);
+      ts_hit = Ts;
+      vx = hx, vy = hy, vz = hz;
       vw = 0.f;
       if (deferred)
         n0 = px, n1 = py, n2 = pz;  // the point itself, for the slab that holds its surroundings
@@ -753,12 +777,7 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
   }
   if (p.depth)
   {
-    unsigned short mm_out = 0;
-    if (hit)
-    {  // static_cast<ushort>(vertex.z * 1000): truncating, saturating conversion
-      const float mm = vz * 1000.f;
-      mm_out = (unsigned short)(mm >= 65535.f ? 65535 : (mm > 0.f ? (int)mm : 0));
-    }
+    const unsigned short mm_out = hit ? vertex_depth_mm(vz) : (unsigned short)0;
     unsigned short* drow = (unsigned short*)(p.depth + (size_t)y * p.depth_pitch);
     drow[x] = mm_out;
   }
@@ -786,8 +805,50 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
     // the pair that ended the march here (zero crossing = 1, abort = 3), or "none": 2 * k + (1 if the
     // normal is still to be computed where the refined point lies)
     int* krow = (int*)(p.keys + (size_t)y * p.keys_pitch);
-    krow[x] = (state == 1 || state == 3) ? 2 * pair + (deferred ? 1 : 0) : 0x7fffffff;
+    const int key = (state == 1 || state == 3) ? 2 * pair + (deferred ? 1 : 0) : 0x7fffffff;
+    krow[x] = key;
+    if (p.key_out)  // yakhip_raycast_sharded: what its composite exchanges
+    {
+      p.key_out[(size_t)y * p.cols + x] = key;
+      p.ts_out[(size_t)y * p.cols + x] = ts_hit;
+    }
   }
+}
+
+// The composite of the slab ray casts (comm.hip), last step: pixel i's winner sent {march time, normal}; the refined
+// point is ray origin + direction * time and the vertex its image in the camera frame, by the instructions the ray
+// cast itself ran (pixel_ray, ray_vertex), the depth follows from the vertex.  An odd key (the normal is still to be
+// computed by the slab that holds the point: raycast_resolve_kernel) gets the point in place of the normal, as
+// raycast_kernel leaves it.  A NaN time: the march ended without a hit (the - to + abort, a NaN normal).
+__global__ __launch_bounds__(256) void composite_unpack_kernel(const RaycastParams p, const int32_t* best, const uint32_t* packed)
+{
+  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+  const int n = p.rows * p.cols;
+  if (i >= n)
+    return;
+  const int y = i / p.cols, x = i - y * p.cols;
+  const int32_t b = best[i];
+  const float qnan = __builtin_nanf("");
+  const float Ts = __builtin_bit_cast(float, packed[i]);
+  float4 v = make_float4(qnan, qnan, qnan, qnan), nr = v;
+  unsigned short mm = 0;
+  if (b != 0x7fffffff && !(Ts != Ts))
+  {
+    float dx, dy, dz, px, py, pz, vx, vy, vz;
+    pixel_ray(p, x, y, dx, dy, dz);
+    ray_vertex(p, dx, dy, dz, Ts, px, py, pz, vx, vy, vz);
+    v = make_float4(vx, vy, vz, 0.f);
+    nr = (b & 1) ? make_float4(px, py, pz, 0.f)
+                 : make_float4(__builtin_bit_cast(float, packed[(size_t)n + i]), __builtin_bit_cast(float, packed[2 * (size_t)n + i]),
+                               __builtin_bit_cast(float, packed[3 * (size_t)n + i]), 0.f);
+    mm = vertex_depth_mm(vz);
+  }
+  if (p.points)
+    ((float4*)(p.points + (size_t)y * p.points_pitch))[x] = v;
+  ((float4*)(p.normals + (size_t)y * p.normals_pitch))[x] = nr;
+  if (p.depth)
+    ((unsigned short*)(p.depth + (size_t)y * p.depth_pitch))[x] = mm;
+  ((int*)(p.keys + (size_t)y * p.keys_pitch))[x] = b;
 }
 
 // Slab mode, after the composite: the pixels whose key is odd hold a refined point (volume frame, in the
@@ -974,6 +1035,13 @@ int launch_raycast_resolve(yakhip_ctx* ctx, const RaycastParams& p)
   else
     hipLaunchKernelGGL((raycast_resolve_kernel<false>), grid, dim3(256), 0, ctx->stream, p);
   return check(hipGetLastError(), "raycast_resolve_kernel launch");
+}
+
+int launch_composite_unpack(yakhip_ctx* ctx, const RaycastParams& p, const int32_t* best, const uint32_t* packed)
+{
+  const unsigned blocks = (unsigned)(((long long)p.rows * p.cols + 255) / 256);
+  hipLaunchKernelGGL(composite_unpack_kernel, dim3(blocks), dim3(256), 0, ctx->stream, p, best, packed);
+  return check(hipGetLastError(), "composite_unpack_kernel launch");
 }
 
 int launch_raycast(yakhip_ctx* ctx, const RaycastParams& p)

@@ -70,6 +70,7 @@ struct yakhip_ctx
   void* static_scratch;  // this device's copy of integrate.hip's file-scope scratch array (yakhip_integrate_static)
   void* icp_scratch;   // ICP: workgroup partials + the reduced 33 values (device)
   size_t icp_scratch_bytes;
+  float* icp_sums;     // sharded ICP, host-solve path: the band's 33 values between accumulate and all-reduce (device)
   void* icp_pinned;    // ICP: pinned host mirror of the 33 values / the state; +128 the state and +192 the ticket icp_solve_kernel writes
   unsigned icp_ticket; // tickets handed out to yakhip_icp_estimate calls
   int icp_poll;        // the host polls that ticket (default) / copies and synchronises
@@ -217,6 +218,10 @@ struct RaycastParams
   uint8_t* keys;
   uint32_t keys_pitch;
   int z_base, z_held, z_own0, z_own1;
+  // yakhip_raycast_sharded only (else null): per pixel, row-major without padding, the key once more and the march time
+  // of the hit's refined point (NaN without a hit) -- what the composite ships instead of the vertex (comm.hip)
+  int32_t* key_out;
+  float* ts_out;
   // surface map of the held layers (yakhip_volume.surface_map) or nullptr: one bit per 16^3 brick, skip_x x skip_y
   // bricks per brick layer, skip_words 32-bit words in all
   const uint32_t* skip;
@@ -314,8 +319,13 @@ struct CompositeImages
 int comm_allreduce(yakhip_ctx* ctx, yakhip_comm* comm, void* buf, size_t count, int op);  // on ctx->stream
 int comm_rank(const yakhip_comm* c);
 int comm_world(const yakhip_comm* c);
-int composite_first(yakhip_ctx* ctx, yakhip_comm* comm, const CompositeImages& im, int cap_request);
+// (scratch of the communicator for an image of n pixels: where the slab ray cast leaves its keys and march times)
+int composite_buffers(yakhip_ctx* ctx, yakhip_comm* comm, int n, int cap_request, int32_t** keys_flat, float** ts_flat);
+int composite_first(yakhip_ctx* ctx, yakhip_comm* comm, const RaycastParams& rp, int cap_request);
 int composite_second(yakhip_ctx* ctx, yakhip_comm* comm, const CompositeImages& im, int cap_request);
+// raycast.hip: the composited pixel from {march time, normal}: the vertex and the depth are rebuilt with the ray cast's own
+// arithmetic; keys <- best
+int launch_composite_unpack(yakhip_ctx* ctx, const RaycastParams& p, const int32_t* best, const uint32_t* packed);
 int composite_status(yakhip_ctx* ctx, yakhip_comm* comm, unsigned out[2]);
 // icp.hip: the device-resident schedule over row bands, the 33 sums of every linearisation all-reduced on the stream
 int launch_icp_estimate_sharded(yakhip_ctx* ctx, yakhip_comm* comm, const float R[9], const float t[3], const float intr[4],
