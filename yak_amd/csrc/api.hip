@@ -139,6 +139,7 @@ int yakhip_ctx_create(yakhip_ctx** out, int device)
   ctx->surface_skip = 1;
   ctx->raycast_bands = -1;
   ctx->raycast_segments = 0;
+  ctx->batch_as_singles = 0;
   if (const char* e = getenv("YAK_HIP_RAYCAST_SEGMENTS"))  // (tuning / tests: 1, 2 or 4 waves per ray)
     if ((e[0] == '1' || e[0] == '2' || e[0] == '4') && e[1] == 0)
       ctx->raycast_segments = e[0] - '0';

@@ -131,15 +131,27 @@ __device__ __forceinline__ float fetch_tsdf_skip(const RaycastParams& p, rsrc_t 
   return half_bits_to_float(word & 0xffffu);
 }
 
-// The brick bit alone, whole volume: is the sample's brick marked?  (fetch_tsdf_skip's own index arithmetic.)
-__device__ __forceinline__ bool sample_brick_marked(const RaycastParams& p, const uint32_t* map_lds, float px, float py, float pz)
+// The brick bit alone: is the sample's brick marked?  (fetch_tsdf_skip's own index arithmetic.)  Slab mode: a sample in a
+// layer that is not held has no brick and reads 0 (`in` cleared); `owned` as in fetch_tsdf_skip.
+template <bool SLAB>
+__device__ __forceinline__ bool sample_brick_marked(const RaycastParams& p, const uint32_t* map_lds, float px, float py, float pz,
+                                                    bool& in, bool& owned)
 {
   const int x = clamp_index((int)__builtin_rintf(px * p.ivx), p.X - 1);
   const int y = clamp_index((int)__builtin_rintf(py * p.ivy), p.Y - 1);
   const int z = clamp_index((int)__builtin_rintf(pz * p.ivz), p.Z - 1);
+  int zl = z;
+  in = true;
+  if constexpr (SLAB)
+  {
+    owned = z >= p.z_own0 && z < p.z_own1;
+    zl = z - p.z_base;
+    in = (unsigned)zl < (unsigned)p.z_held;
+    zl = in ? zl : 0;
+  }
   const uint32_t b = (uint32_t)(x >> kSkipShift) +
-                     __umul24((uint32_t)p.skip_x, (uint32_t)(y >> kSkipShift) + __umul24((uint32_t)p.skip_y, (uint32_t)(z >> kSkipShift)));
-  return (map_lds[b >> 5] >> (b & 31u)) & 1u;
+                     __umul24((uint32_t)p.skip_x, (uint32_t)(y >> kSkipShift) + __umul24((uint32_t)p.skip_y, (uint32_t)(zl >> kSkipShift)));
+  return in && ((map_lds[b >> 5] >> (b & 31u)) & 1u);
 }
 
 // tsdf_volume.cu:167-192: trilinear tap, argument in voxel units
@@ -505,7 +517,7 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
         }
       }
       constexpr int kUnroll = SKIP ? YAK_RAYCAST_UNROLL_SKIP : kUnrollPlain;
-      if constexpr (SKIP && !SLAB)
+      if constexpr (SKIP)
       {
         // A look at the bricks before anything else.  Inside a marked cell most samples still lie in unmarked bricks
         // (six trips in seven fetch nothing): if none of this trip's samples, in any lane still marching, lies in a
@@ -515,6 +527,7 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
         // trip to reuse, costs the quiet trips more than it saves the others.)
         float bx = nx, by = ny, bz = nz;
         bool marked = tsdf_next < 0.f;
+        bool last_in = true, last_owned = true;  // (slab mode: a sample outside the held layers reads 0, like a skipped one)
         if (look_first)
         {
 #pragma unroll
@@ -523,7 +536,7 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
             bx += sx;
             by += sy;
             bz += sz;
-            marked = marked | sample_brick_marked(p, map_lds, bx, by, bz);
+            marked = marked | sample_brick_marked<SLAB>(p, map_lds, bx, by, bz, last_in, last_owned);
           }
         }
         // (a wave that has just fetched does not look first: beside a surface one trip after the other fetches; it
@@ -550,7 +563,8 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
             }
           }
           nx = bx, ny = by, nz = bz;
-          tsdf_next = 0.f, skip_next = true;  // an unmarked brick's sample: +0, not fetched
+          tsdf_next = 0.f, skip_next = last_in;  // an unmarked brick's sample: +0, not fetched (not held: 0 for good)
+          own_next = last_owned;
           continue;
         }
         look_first = false;
@@ -571,12 +585,12 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
         else
           f[k] = fetch_tsdf<IDX32, SLAB>(p, ax, ay, az, own[k], held[k]);
       }
-      if constexpr (SKIP && !SLAB)
+      if constexpr (SKIP)
       {
         bool all_skipped = true;
 #pragma unroll
         for (int k = 0; k < kUnroll; ++k)
-          all_skipped = all_skipped & skip[k];
+          all_skipped = all_skipped & (skip[k] | (SLAB && !held[k]));
         look_first = __ballot(!all_skipped) == 0ull;
       }
       if constexpr (SKIP)

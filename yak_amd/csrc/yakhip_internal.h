@@ -27,6 +27,7 @@ struct yakhip_ctx
   int chunk_ramp;      // 0 automatic (6); a chunk starting at layer zs is about zs / ramp layers long; -1: all chunks alike (tuning)
   int raycast_bands;   // ray-cast tiles: -1 automatic, 1 each XCD a contiguous band of the image, 0 image order, >= 2 scattered
   int surface_skip;    // the ray cast consults a volume's surface map (default) / ignores it
+  int batch_as_singles;  // set while yakhip_integrate_batch runs its frames as single-frame launches (integrate.hip)
   int raycast_segments;  // waves per ray with the surface map: 0 the default, 1 one wave marches the whole ray, 2 or 4
   int brick_test;      // classify whole bricks (dead / front / mixed) before walking them (default) / off
   int checkpoint;      // deep slabs start from closed-form column positions (default) / replay from layer 0
