@@ -46,7 +46,10 @@ constexpr int kDefaultTileShift = 6;  // wave footprint in a layer, see lane_vox
 constexpr int kMixedWavesPerSimd = 5;  // size of integrate_list_kernel's grid: workgroups per CU
 constexpr uint64_t kTwoKernelMinVoxels = 1ull << 25;  // smaller slabs are one kernel unless "defer_mixed" is 2
 constexpr int kPartLayers = 8;         // a listed brick is walked in parts of this many layers (at most four parts)
-constexpr int kCheckpointStride = 32;  // layers between the column checkpoints of a launch with a list
+#ifndef YAK_CP_STRIDE
+#define YAK_CP_STRIDE 32
+#endif
+constexpr int kCheckpointStride = YAK_CP_STRIDE;  // layers between the column checkpoints of a launch with a list
 // layers per part of a brick of `layers` layers: kPartLayers, or what makes four parts of a longer brick (even)
 __host__ __device__ inline int part_layers(int layers)
 {
