@@ -28,7 +28,10 @@ def main():
         ctx.set_option("icp_poll", 0)
     run_kinfu_loop(ctx, args.n, 8, "device", overlap=not args.no_overlap, prepare=not args.no_prepare)  # warm-up
     mode = None if args.no_icp else ("host" if args.host_icp else "device")
+    c0 = ctx.launch_counts()
     r = run_kinfu_loop(ctx, args.n, args.frames, mode, overlap=not args.no_overlap, prepare=not args.no_prepare)
+    c1 = ctx.launch_counts()
+    print("integrate launches: %s" % {k: c1[k] - c0[k] for k in c1})
     print("%d^3, %d frames of the S2 orbit, ICP %s: %.1f frames/s (wall %.3f s); worst position error %.1f mm" % (
         r["n"], r["frames"], {None: "off (true poses)", "host": "on (host loop)", "device": "on (device loop)"}[mode],
         r["frames_per_s"], r["wall_s"], r["worst_position_error_mm"]))

@@ -2058,8 +2058,12 @@ static int prepare_frame(yakhip_ctx* ctx, IntegrateParams& p, int slot, int slot
     const uint32_t ckpt_blocks = p.ckpt ? (p.plane + 255u) / 256u : 0u;
     const uint32_t brick_blocks = (uint32_t)((p.ccw * p.cch + 3) / 4);
     const uint32_t fine_blocks = two ? (uint32_t)((p.fcw * p.fch + 255) / 256) : 0u;  // (only the two-kernel launch looks at them)
-    // (one more workgroup sums up the class bytes of the launch before this one: see prepass_kernel)
-    const uint32_t stats_blocks = !ahead && !use_static && slot == 0 && ctx->classes && ctx->classes_n != 0 && ctx->stats_host ? 1u : 0u;
+    // (one more workgroup sums up the class bytes of the launch before this one: see prepass_kernel.  A prepass ahead of
+    // time runs beside that launch: it then sums bytes of which some are still those of the launch before -- each byte
+    // is a whole class either way, and "what the last two frames looked like" is all the findings are used for.  Without
+    // this a loop that prepares every frame never had findings, and every frame of it ran as one kernel.)
+    const uint32_t stats_blocks =
+        !use_static && (ahead || slot == 0) && ctx->classes && ctx->classes_n != 0 && ctx->stats_host ? 1u : 0u;
     hipLaunchKernelGGL(prepass_kernel, dim3(thr_blocks + cell_blocks + brick_blocks + fine_blocks + stats_blocks + ckpt_blocks),
                        dim3(256), 0, ctx->stream, p.dists, p.dists_pitch, p.rows, p.cols, p.trunc_hi, (f32x2*)base,
                        (float*)(base + thr_bytes), p.cw, p.ch, bk, thr_blocks_x, thr_blocks, ckpt_blocks, p,
