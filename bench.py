@@ -454,7 +454,11 @@ def orbit_views_row(ctx, torch, capi, synth):
             "launches": {k: counts1[k] - counts0[k] for k in counts1},
             "kernels": "yakhip::classify_kernel<4> + yakhip::integrate_list_kernel<4, true> (two kernels: one event pair around "
                        "both) or yakhip::integrate_kernel<4, true>, see `launches`",
-            "valu_instructions": load_traffic("integrate_orbit_views_valu"),
+            "valu_instructions": load_record("integrate_orbit_views_valu", ("round2_kernel", "round3_two_kernels",
+                                                                            "round3_one_kernel", "source")),
+            "valu_instructions_per_updated_voxel": (round(load_record("integrate_orbit_views_valu", ("round3_two_kernels",))
+                                                          ["round3_two_kernels"] * 64 / mean_upd, 1)
+                                                    if load_record("integrate_orbit_views_valu", ("round3_two_kernels",)) else None),
             "note": "bound by the per-voxel path of the bricks that hold surface, not by HBM: only updated voxels "
                     "count as algorithmic bytes (SURVEY.md 8d)"}
 
@@ -708,6 +712,16 @@ def load_traffic(workload_key):
             rec = json.load(f)
         ent = rec.get(workload_key)
         return ent.get("hbm_bytes_per_launch") if ent else None
+    except (OSError, ValueError):
+        return None
+
+
+def load_record(key, fields):
+    """Selected fields of an entry of profiles/traffic.json (committed counter passes), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            ent = json.load(f).get(key)
+        return {k: ent[k] for k in fields if k in ent} if ent else None
     except (OSError, ValueError):
         return None
 

@@ -51,8 +51,8 @@ w, _ = mean_kib(write, "WRITE_SIZE", "integrate_kernel<4, true>")
 out["integrate_s0_n1"] = {"kernel": "yakhip::integrate_kernel<4, true>", "launches": n, "FETCH_SIZE_KiB": round(f), "WRITE_SIZE_KiB": round(w),
                           "fetch_bytes_corrected": int(round(f) * 2048), "write_bytes": int(round(w) * 1024),
                           "hbm_bytes_per_launch": int(round(f) * 2048 + round(w) * 1024), "source": how}
-for key, kern, what in (("raycast_s2_n1", "raycast_kernel<true, false, true>", "with the surface map"),
-                        ("raycast_s2_n1_without_surface_map", "raycast_kernel<true, false, false>", "without the surface map")):
+for key, kern, what in (("raycast_s2_n1", "raycast_kernel<true, false, true, 1>", "with the surface map"),
+                        ("raycast_s2_n1_without_surface_map", "raycast_kernel<true, false, false, 1>", "without the surface map")):
     f, n = mean_kib(fetch, "FETCH_SIZE", kern)
     w, _ = mean_kib(write, "WRITE_SIZE", kern)
     out[key] = {"kernel": "yakhip::" + kern, "what": "mean over the five orbit views bench.py times, " + what, "launches": n,

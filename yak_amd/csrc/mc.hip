@@ -518,8 +518,8 @@ __device__ __forceinline__ bool cloud_voxel(uint32_t word, float& F)
 }
 
 template <bool EMIT>
-__global__ __launch_bounds__(256) void cloud_kernel(const CloudParams p, uint32_t* counts, const uint32_t* local_offsets,
-                                                    const unsigned long long* block_bases, float4* points)
+__global__ __launch_bounds__(256) void cloud_kernel(const CloudParams p, uint32_t* counts, const unsigned long long* list,
+                                                    unsigned long long n_live, float4* points)
 {
   const int lane = (int)threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   // count pass: every XCD gets a contiguous run of workgroups (shared lines and rows meet in one L2); the
@@ -528,13 +528,27 @@ __global__ __launch_bounds__(256) void cloud_kernel(const CloudParams p, uint32_
   const unsigned wg =
       !EMIT && blockIdx.x < per_xcd * 8u ? (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u : blockIdx.x;
   const unsigned gy = (unsigned)(p.ny + 3) / 4u;
-  const int xt = (int)(wg % (unsigned)p.nx), yt = (int)((wg / (unsigned)p.nx) % gy) * 4 + wave,
-            zc = (int)(wg / ((unsigned)p.nx * gy));
-  if (yt >= p.ny)
-    return;
   const int walk = EMIT ? p.z_sub : p.z_chunk;
   const size_t tile_stride = (size_t)p.ny * p.nx;
-  size_t tile = ((size_t)zc * (size_t)(walk / p.z_sub) * p.ny + yt) * p.nx + xt;
+  int xt, yt, zc;
+  size_t tile;
+  unsigned long long out = 0;
+  if (EMIT)  // (launched over the tiles that hold points: wave k takes entry k of the list, as mc_kernel's emit pass)
+  {
+    const unsigned long long k = (unsigned long long)blockIdx.x * 4ull + (unsigned long long)wave;
+    if (k >= n_live)
+      return;
+    tile = (size_t)list[2 * k];
+    out = list[2 * k + 1];
+    xt = (int)(tile % (size_t)p.nx), yt = (int)((tile / (size_t)p.nx) % (size_t)p.ny), zc = (int)(tile / tile_stride);
+  }
+  else
+  {
+    xt = (int)(wg % (unsigned)p.nx), yt = (int)((wg / (unsigned)p.nx) % gy) * 4 + wave, zc = (int)(wg / ((unsigned)p.nx * gy));
+    if (yt >= p.ny)
+      return;
+    tile = ((size_t)zc * (size_t)(walk / p.z_sub) * p.ny + yt) * p.nx + xt;
+  }
   if (!EMIT && p.map)
   {
     // A point needs a pair of voxels of opposite strict sign, one of them negative, and a brick whose bit is clear
@@ -559,14 +573,6 @@ __global__ __launch_bounds__(256) void cloud_kernel(const CloudParams p, uint32_
       return;
     }
   }
-  unsigned long long out = 0;
-  if (EMIT)
-  {
-    if (counts[tile] == 0)
-      return;
-    out = block_bases[tile / kScanBlock] + local_offsets[tile];
-  }
-
   const int x = xt * kRun + lane, y0 = yt * kRows;
   const bool in_x = x < p.X;
   const bool owner = lane < kRun && in_x;       // this lane's voxels are counted here
@@ -844,37 +850,37 @@ int launch_extract_cloud(yakhip_ctx* ctx, const uint32_t* vol, int X, int Y, int
   const size_t n_tiles = (size_t)p.nx * p.ny * p.nzs, wgs_layer = (size_t)p.nx * gy;
   if (wgs_layer * (size_t)p.nzs > 0x7fffffffull)
     return fail(YAKHIP_ERANGE, "extract_cloud: more than 2^31 workgroups");
-  uint32_t *counts, *local_offsets;
-  unsigned long long *block_bases, *total;
-  size_t n_blocks;
   TileScratch ts;
-  int rc = tile_scratch(ctx, n_tiles, false, &ts);
-  counts = ts.counts, local_offsets = ts.local_offsets, block_bases = ts.block_bases, total = ts.total, n_blocks = ts.n_blocks;
+  int rc = tile_scratch(ctx, n_tiles, true, &ts);
   if (rc != 0)
     return rc;
 
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   if ((rc = timing_begin(ctx, &ev)) != 0)
     return rc;
-  hipLaunchKernelGGL((cloud_kernel<false>), dim3((unsigned)(wgs_layer * p.nzc)), dim3(256), 0, ctx->stream, p, counts,
-                     local_offsets, block_bases, (float4*)nullptr);
+  hipLaunchKernelGGL((cloud_kernel<false>), dim3((unsigned)(wgs_layer * p.nzc)), dim3(256), 0, ctx->stream, p, ts.counts,
+                     (const unsigned long long*)nullptr, 0ull, (float4*)nullptr);
   YAKHIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(mc_scan_local_kernel, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, counts, local_offsets,
-                     n_tiles, block_bases, (uint32_t*)nullptr, (unsigned long long*)nullptr);
-  hipLaunchKernelGGL(mc_scan_blocks_kernel, dim3(1), dim3(1024), 0, ctx->stream, block_bases, n_blocks, total);
+  hipLaunchKernelGGL(mc_scan_local_kernel, dim3((unsigned)ts.n_blocks), dim3(256), 0, ctx->stream, ts.counts, ts.local_offsets,
+                     n_tiles, ts.block_bases, ts.live_local, ts.block_live);
+  hipLaunchKernelGGL(mc_scan_blocks_kernel, dim3(2), dim3(1024), 0, ctx->stream, ts.block_bases, ts.n_blocks, ts.total);
+  hipLaunchKernelGGL(mc_compact_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, ctx->stream, ts.counts,
+                     ts.local_offsets, ts.block_bases, ts.live_local, ts.block_live, n_tiles, ts.list);
   if ((rc = timing_end(ctx, ev)) != 0)
     return rc;
   YAKHIP_TRY(hipGetLastError());
-  YAKHIP_TRY(hipMemcpyAsync(ctx->mc_pinned, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  YAKHIP_TRY(hipMemcpyAsync(ctx->mc_pinned, ts.total, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   YAKHIP_TRY(hipStreamSynchronize(ctx->stream));
-  const unsigned long long n = *(const unsigned long long*)ctx->mc_pinned;
+  const unsigned long long n = ((const unsigned long long*)ctx->mc_pinned)[0];
+  const unsigned long long n_live = ((const unsigned long long*)ctx->mc_pinned)[1];
   *n_out = n;
   if (!points || n == 0 || capacity == 0)
     return 0;
   if ((rc = timing_begin(ctx, &ev)) != 0)
     return rc;
-  hipLaunchKernelGGL((cloud_kernel<true>), dim3((unsigned)(wgs_layer * p.nzs)), dim3(256), 0, ctx->stream, p, counts,
-                     local_offsets, block_bases, (float4*)points);
+  // (the emit pass over the tiles that hold points only, like marching cubes')
+  hipLaunchKernelGGL((cloud_kernel<true>), dim3((unsigned)((n_live + 3) / 4)), dim3(256), 0, ctx->stream, p, ts.counts, ts.list,
+                     n_live, (float4*)points);
   if ((rc = timing_end(ctx, ev)) != 0)
     return rc;
   YAKHIP_TRY(hipGetLastError());
