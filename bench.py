@@ -221,12 +221,13 @@ def next_rows(ctx, torch, capi, synth, with_cpu):
     out["marching_cubes"]["weld_vertices"] = {"ms_blocking": round((time.perf_counter() - t0) / 5 * 1e3, 4),
                                               "corners": 3 * ntri, "vertices": nvert}
     del wv, wi
-    # cloud extraction (count, scan, emit): 2 reads of the volume + 16 B per point
+    # cloud extraction (count, scan, list, emit over the tiles that hold points): ONE read of the volume + 16 B per point,
+    # the same definition as marching cubes' (two reads were counted here until the emit pass stopped re-reading the volume)
     npts = ctx.extract_cloud(plain, np.eye(3).reshape(-1), np.zeros(3))
     cloud = torch.empty((max(npts, 1), 4), dtype=torch.float32, device="cuda")
     ms = timed(lambda: ctx.extract_cloud(plain, np.eye(3).reshape(-1), np.zeros(3), cloud.data_ptr(), npts), 5)
     ms_map = timed(lambda: ctx.extract_cloud(desc, np.eye(3).reshape(-1), np.zeros(3), cloud.data_ptr(), npts), 5)
-    cl_bytes = 2 * 4 * n ** 3 + 16 * npts
+    cl_bytes = 4 * n ** 3 + 16 * npts
     out["extract_cloud"] = {"ms_both_passes": round(ms, 4), "ms_both_passes_with_surface_map": round(ms_map, 4), "points": npts,
                             "algorithmic_bytes": cl_bytes,
                             "achieved_GBps": round(cl_bytes / (ms * 1e-3) / 1e9, 1),
