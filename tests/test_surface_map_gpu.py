@@ -299,6 +299,33 @@ def test_raycast_512_with_the_map_on_a_volume_fused_on_the_gpu(gpu_ctx):
         assert same_bits(raycast(gpu_ctx, s.desc, R, t, R_v2c, synth.INTR, rows, cols), plain)
 
 
+@pytest.mark.parametrize("n,layers", [(1024, 528), (1024, 1024)])
+def test_raycast_with_the_map_on_volumes_of_2_gib_and_more(gpu_ctx, n, layers):
+    """Held layers of 2 GiB and more do not fit the buffer descriptor the samples of smaller volumes are read through
+    (raycast.hip, fetch_tsdf_skip<..., BIG>), and a 1024^3 volume's map is 8320 words of LDS: the ray cast with the map
+    must still be the ray cast without it, bit for bit (which the oracle pins at the sizes it finishes)."""
+    dims, vs, tr = synth.volume_geometry(n)
+    dims = (dims[0], dims[1], layers)
+    s = Slab(dims, vs, tr)
+    assert int(np.prod(dims)) * 4 >= 2 ** 31
+    gpu_ctx.clear_volume(s.desc)
+    rows, cols = synth.ROWS, synth.COLS
+    frames = orbit_frames(list(range(0, 300, 50)))
+    dev = [dev_u16_image(d) for d, _, _ in frames]
+    for dd, (_, R, t) in zip(dev, frames):
+        gpu_ctx.integrate(s.desc, dd.data_ptr(), cols * 2, rows, cols, R.reshape(-1), t, synth.INTR)
+    for view in (0, 100, 222):
+        _, R_v2c, t_v2c = synth.scene_s2(view)
+        R, t = cam2vol(R_v2c, t_v2c)
+        plain = raycast(gpu_ctx, s.plain, R, t, R_v2c, synth.INTR, rows, cols)
+        assert (~np.isnan(plain[0][..., 0])).sum() > 20000
+        assert same_bits(raycast(gpu_ctx, s.desc, R, t, R_v2c, synth.INTR, rows, cols), plain)
+        assert same_bits(raycast(gpu_ctx, s.desc, R, t, R_v2c, synth.INTR, rows, cols, depth=True),
+                         raycast(gpu_ctx, s.plain, R, t, R_v2c, synth.INTR, rows, cols, depth=True))
+    del s
+    torch.cuda.empty_cache()
+
+
 def test_marching_cubes_and_cloud_with_the_map_give_the_same_output(gpu_ctx):
     """The count pass leaves out what no marked brick is near; the triangle list is the same, entry for entry --
     whole slab, a slab that starts inside the volume, and a layer range of a slab (yakhip_marching_cubes_layers)."""

@@ -35,7 +35,9 @@ constexpr int kUnrollPlain = 4;
 #define YAK_RAYCAST_UNROLL_SKIP 8
 #endif
 constexpr int kDefaultSegments = 1;  // waves per ray when the surface map is consulted (raycast_kernel, SEG)
-constexpr int kMaxSkipWords = 8192;  // 32 KiB of LDS: 2^18 bricks, e.g. 1024^3 voxels or a 2048 x 2048 x 256 slab
+// 48 KiB of LDS at most for the map (three workgroups a CU then; up to 32 KiB -- 512^3: 4 KiB -- five): a 1024^3 volume
+// needs 8192 words of brick bits + 128 of cell bits, a 2048 x 2048 x 276 slab of configuration 5 9376
+constexpr int kMaxSkipWords = 12288;
 
 template <bool IDX32>
 __device__ __forceinline__ float voxel_tsdf(const RaycastParams& p, int x, int y, int z)
@@ -105,7 +107,7 @@ __device__ __forceinline__ int clamp_index(int v, int hi)
 }
 // (index arithmetic in 24-bit multiply-adds, full rate where the 32-bit ones run at a quarter: the launcher takes this
 // variant only for X, Y < 2^24 and Y * held layers <= 2^24)
-template <bool SLAB>
+template <bool SLAB, bool BIG>
 __device__ __forceinline__ float fetch_tsdf_skip(const RaycastParams& p, rsrc_t rs, const uint32_t* map_lds, float px, float py,
                                                  float pz, bool& owned, bool& held, bool& skipped)
 {
@@ -127,8 +129,20 @@ __device__ __forceinline__ float fetch_tsdf_skip(const RaycastParams& p, rsrc_t 
   const bool marked = (map_lds[b >> 5] >> (b & 31u)) & 1u;
   skipped = in && !marked;
   const uint32_t idx = (uint32_t)x + __umul24((uint32_t)p.X, (uint32_t)y + __umul24((uint32_t)p.Y, (uint32_t)zl));
-  const uint32_t word = __builtin_amdgcn_raw_buffer_load_b32(rs, in && marked ? idx << 2 : 0x80000000u, 0, 0);
-  return half_bits_to_float(word & 0xffffu);
+  if constexpr (BIG)
+  {
+    // held layers of 2 GiB and more (a 1024^3 volume: 4 GiB) do not fit the descriptor's offsets: a load under the
+    // lane's predicate instead (the voxel index still fits 32 bits: the launcher sees to it)
+    uint32_t word = 0;
+    if (in && marked)
+      word = p.vol[(size_t)idx];
+    return half_bits_to_float(word & 0xffffu);
+  }
+  else
+  {
+    const uint32_t word = __builtin_amdgcn_raw_buffer_load_b32(rs, in && marked ? idx << 2 : 0x80000000u, 0, 0);
+    return half_bits_to_float(word & 0xffffu);
+  }
 }
 
 // The brick bit alone: is the sample's brick marked?  (fetch_tsdf_skip's own index arithmetic.)  Slab mode: a sample in a
@@ -397,10 +411,10 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
   {
     bool own_next = true, scratch = true, skip_next = false;
     float tsdf_next;
-    // (SKIP only; the launcher takes this variant only for held layers below 2 GiB)
-    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.vol), 0, (uint32_t)p.vol_bytes, 0x00020000);
+    // (SKIP only; held layers below 2 GiB are read through it, larger ones -- the IDX32 = false variants -- by plain loads)
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.vol), 0, IDX32 ? (uint32_t)p.vol_bytes : 0u, 0x00020000);
     if constexpr (SKIP)
-      tsdf_next = fetch_tsdf_skip<SLAB>(p, rs, map_lds, nx, ny, nz, own_next, scratch, skip_next);
+      tsdf_next = fetch_tsdf_skip<SLAB, !IDX32>(p, rs, map_lds, nx, ny, nz, own_next, scratch, skip_next);
     else
       tsdf_next = fetch_tsdf<IDX32, SLAB>(p, nx, ny, nz, own_next, scratch);
     if constexpr (SKIP)
@@ -581,7 +595,7 @@ __global__ __launch_bounds__(256, 5) void raycast_kernel(const RaycastParams p, 
         qx[k] = ax, qy[k] = ay, qz[k] = az;
         own[k] = true, held[k] = true, skip[k] = false;
         if constexpr (SKIP)
-          f[k] = fetch_tsdf_skip<SLAB>(p, rs, map_lds, ax, ay, az, own[k], held[k], skip[k]);
+          f[k] = fetch_tsdf_skip<SLAB, !IDX32>(p, rs, map_lds, ax, ay, az, own[k], held[k], skip[k]);
         else
           f[k] = fetch_tsdf<IDX32, SLAB>(p, ax, ay, az, own[k], held[k]);
       }
@@ -1063,7 +1077,10 @@ int launch_raycast(yakhip_ctx* ctx, const RaycastParams& p)
   const bool slab = p.keys != nullptr;
   // the surface map travels in LDS: volumes whose map is too large for that are marched without it
   // (and it does its index arithmetic in 24 bits: fetch_tsdf_skip)
-  const bool skip = p.skip != nullptr && p.skip_words + p.cell_words <= kMaxSkipWords && p.vol_bytes < 0x80000000ull &&
+  // (held layers of 2 GiB and more take the variants that index in 64 bits -- IDX32 = false -- whose sample fetches are
+  // plain loads; the voxel index itself must fit 32 bits)
+  const unsigned long long held_voxels = (unsigned long long)p.X * (unsigned long long)p.Y * (unsigned long long)p.z_held;
+  const bool skip = p.skip != nullptr && p.skip_words + p.cell_words <= kMaxSkipWords && held_voxels <= 0xffffffffull &&
                     p.X < (1 << 24) && p.Y < (1 << 24) && (long long)p.Y * p.z_held <= (1ll << 24) && ctx->surface_skip;
   // segments per ray (raycast_kernel, SEG): whole volume with the surface map only
   const int seg = skip && !slab ? (ctx->raycast_segments > 0 ? ctx->raycast_segments : kDefaultSegments) : 1;
@@ -1075,8 +1092,10 @@ int launch_raycast(yakhip_ctx* ctx, const RaycastParams& p)
   const int n_tiles = (int)n_tiles_ll;
   const int per_xcd = (n_tiles + 7) / 8;
   const dim3 grid((unsigned)(per_xcd * 8));
-  const bool idx32 =
-      (unsigned long long)p.X * (unsigned long long)p.Y * (unsigned long long)(slab ? p.z_held : p.Z) <= (1ull << 30);
+  // (32-bit byte offsets: up to 2^30 voxels by plain loads, below 2^29 -- 2 GiB -- where the samples come through the
+  // buffer descriptor, whose skipped lanes pass the offset 2^31)
+  const bool idx32 = (unsigned long long)p.X * (unsigned long long)p.Y * (unsigned long long)(slab ? p.z_held : p.Z) <=
+                     (skip ? (1ull << 29) - 1ull : (1ull << 30));
 
   std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
   int rc = timing_begin(ctx, &ev);
