@@ -471,8 +471,8 @@ int yakhip_ctx_set_option(yakhip_ctx* ctx, const char* key, int value)
   }
   if (strcmp(key, "mixed_waves") == 0)
   {
-    if (value < 0 || value > 8)
-      return fail(YAKHIP_EINVAL, "mixed_waves must be 0 (default) or 1..8");
+    if (value < 0 || value > 32)
+      return fail(YAKHIP_EINVAL, "mixed_waves must be 0 (default) or 1..32");
     ctx->mixed_waves = value;
     return 0;
   }
