@@ -1,6 +1,9 @@
 # usage (on the GPU box): bash tools/pmc_valu_before_after.sh  -- VERDICT r2 item 1's evidence: SQ counters per integrate
 # launch on the eight orbit views (tools/bench_views.py --orbit, one wait per frame) for the round-2 tree checked out
-# and built under r02tree/ (git archive d42c2fe; not committed) and for this tree, same box, same run.
+# and built under r02tree/ (not committed; here, before the GPU call:
+#   mkdir r02tree && git archive d42c2fe | tar -x -C r02tree && make -C r02tree/yak_amd/csrc libyakhip.so &&
+#   cp tools/bench_views.py r02tree/tools/ && echo r02tree >> .gitignore
+# ) and for this tree, same box, same run.
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
