@@ -132,6 +132,16 @@ def next_rows(ctx, torch, capi, synth, with_cpu):
         ctx.integrate_batch(plain, frames[4:])
 
     out["integrate_batch_k4_s2_ms_per_frame"] = round(timed(both_batches, 5, wait=True) / 8, 4)
+
+    # ... and the same eight frames as single calls under the same protocol (this volume, one wait per four frames), so that
+    # the two figures differ by the entry point alone
+    def eight_singles():
+        for i, fr in enumerate(frames):
+            ctx.integrate(plain, *fr)
+            if i == 3:
+                torch.cuda.synchronize()
+
+    out["integrate_singles_same_protocol_ms_per_frame"] = round(timed(eight_singles, 5, wait=True) / 8, 4)
     c1 = ctx.launch_counts()
     out["integrate_batch_k4_s2_ran_as"] = ("single-frame launches: %s" % {k: c1[k] - c0[k] for k in c1}
                                            if sum(c1.values()) > sum(c0.values()) else "integrate_batch_kernel<4> sweeps")
@@ -458,7 +468,7 @@ def orbit_views_row(ctx, torch, capi, synth):
             "valu_instructions": load_record("integrate_orbit_views_valu", ("round2_kernel", "round3_two_kernels",
                                                                             "round3_one_kernel", "source")),
             "valu_instructions_per_updated_voxel": (round(load_record("integrate_orbit_views_valu", ("round3_two_kernels",))
-                                                          ["round3_two_kernels"] * 64 / mean_upd, 1)
+                                                          ["round3_two_kernels"] * 64 / mean_upd, 1)  # (wave instructions x 64 lanes)
                                                     if load_record("integrate_orbit_views_valu", ("round3_two_kernels",)) else None),
             "note": "bound by the per-voxel path of the bricks that hold surface, not by HBM: only updated voxels "
                     "count as algorithmic bytes (SURVEY.md 8d)"}
