@@ -1022,13 +1022,31 @@ def main():
             (args.extra_rows and not emulate)):
         vol = None
         torch.cuda.empty_cache()
+        # These rows have never run on multi-GPU hardware (the pool gives one-GPU boxes): if a collective in them should
+        # hang, the headline measured above must still get out.  A watchdog prints the line without them and ends the
+        # process; it is cancelled when the rows are done.
+        import threading
+
+        def give_up():
+            if rank == 0 or emulate:
+                late = dict(out)
+                late.update({k: v for k, v in extra.items() if v is not None})
+                late["extra_rows"] = {"error": "timed out after %d s; rows finished by then are included" % extra_timeout}
+                print(json.dumps(late), flush=True)
+            os._exit(0)
+
+        extra_timeout = int(os.environ.get("YAK_BENCH_EXTRA_TIMEOUT", "480"))
+        watchdog = threading.Timer(extra_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         for key, fn in (("c5", lambda: c5_measure(args, torch, capi, synth, dist, world, rank, local_rank, share_gpu, None,
                                                   steps=min(args.steps, 10), warmup=min(args.warmup, 3), with_cpu=False)),
                         ("kinfu_loop_sharded", lambda: kinfu_loop_sharded_row(ctx, torch, capi, synth, dist, world, rank))):
             try:
                 extra[key] = fn()
             except Exception as e:  # secondary: never take the headline down with it (every rank fails alike or hangs in a
-                extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}  # collective: the driver's time limit ends that)
+                extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}  # collective: the watchdog above ends that)
+        watchdog.cancel()
     if rank == 0 or emulate:
         for k, v in extra.items():
             if v is not None:
