@@ -649,7 +649,10 @@ def c5_measure(args, torch, capi, synth, dist, world, rank, local_rank, share_gp
                        "parallelism": "z-slab x%d" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": load_traffic("integrate_batch_c5_rank%d_of_%d" % (rank, world)),
+                         # (HBM bytes per sweep from committed counter passes of the launch kind that ran: the one sweep
+                         # kernel, or K single-frame launches of two kernels each -- which touch a voxel once per frame)
+                         "traffic": load_traffic(("integrate_batch_c5_rank%d_of_%d" if single_launches == 0 else
+                                                  "integrate_singles_c5_rank%d_of_%d") % (rank, world)),
                          "kernel": sweep_kernel, "kernel_ms": round(kernel_ms, 5),
                          "launches_per_sweep": {"bracketed_kernel_launches": round(kernel_launches / max(n_steps, 1), 2),
                                                 "single_frame_calls_as_one_kernel": (counts1["one_kernel"] - counts0["one_kernel"]) / max(n_steps, 1),
