@@ -333,11 +333,11 @@ def kinfu_loop_sharded_row(ctx, torch, capi, synth, dist, world, rank, frames=SH
     err_mm = float(np.linalg.norm(kf.pose_t - t_true) * 1e3)
 
     # the collectives of one frame on their own (what DESIGN.md 5 tabulates): 19 x 33 floats SUM, the keys MIN, the
-    # payload SUM (7 words per pixel), the settled pixels' list SUM (32 B x max(4096, pixels / 64) slots)
+    # payload SUM (4 words per pixel: march time + normal), the settled pixels' list SUM (16 B x max(4096, pixels / 64) slots)
     small = torch.zeros(64, dtype=torch.float32, device="cuda")
     keys = torch.zeros(rows * cols, dtype=torch.int32, device="cuda")
-    payload = torch.zeros(rows * cols * 7, dtype=torch.int32, device="cuda")
-    slots = torch.zeros(8 * max(4096, rows * cols // 64), dtype=torch.int32, device="cuda")
+    payload = torch.zeros(rows * cols * 4, dtype=torch.int32, device="cuda")
+    slots = torch.zeros(4 * max(4096, rows * cols // 64), dtype=torch.int32, device="cuda")
 
     def timed_coll(fn, reps=10):
         fn()
@@ -356,7 +356,7 @@ def kinfu_loop_sharded_row(ctx, torch, capi, synth, dist, world, rank, frames=SH
 
     coll = {"icp_19_x_33_floats_ms": timed_coll(icp_sums),
             "raycast_keys_min_ms": timed_coll(lambda: ctx.allreduce(kf.comm, keys.data_ptr(), rows * cols, capi.MIN_I32)),
-            "raycast_payload_sum_ms": timed_coll(lambda: ctx.allreduce(kf.comm, payload.data_ptr(), rows * cols * 7, capi.SUM_I32)),
+            "raycast_payload_sum_ms": timed_coll(lambda: ctx.allreduce(kf.comm, payload.data_ptr(), rows * cols * 4, capi.SUM_I32)),
             "raycast_settled_sum_ms": timed_coll(lambda: ctx.allreduce(kf.comm, slots.data_ptr(), slots.numel(), capi.SUM_I32))}
     vals = [elapsed, err_mm] + [stage_ms.get(k, 0.0) for k in ("preprocess", "icp", "integrate", "raycast")] + list(coll.values())
     t = torch.tensor(vals, dtype=torch.float64, device="cpu" if dist is not None and world > 1 and dist.get_backend() == "gloo" else "cuda")
